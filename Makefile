@@ -1,0 +1,31 @@
+# Builds libcat_amd.so (hand-written HIP for gfx950 + the C ABI) and the CPU oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude
+SRC := cat_amd/csrc/capi.cpp cat_amd/csrc/ntt.hip cat_amd/csrc/polyops.hip cat_amd/csrc/keyswitch.hip cat_amd/csrc/bfv.hip
+HDR := include/cat_amd.h cat_amd/csrc/context.hpp cat_amd/csrc/host_math.hpp cat_amd/csrc/modarith.cuh
+OBJ := $(patsubst cat_amd/csrc/%,build/%.o,$(SRC))
+LIB := cat_amd/lib/libcat_amd.so
+
+all: $(LIB) oracle
+
+$(LIB): $(OBJ)
+	@mkdir -p cat_amd/lib
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJ)
+
+build/%.hip.o: cat_amd/csrc/%.hip $(HDR)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+build/%.cpp.o: cat_amd/csrc/%.cpp $(HDR)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,214 @@
+"""Python plumbing over the C ABI (include/cat_amd.h).  Tensors are torch.int64 CUDA tensors whose
+bits are the uint64 words of the reference's layout [..., limb, coeff]."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SCHEME_NONE, SCHEME_BFV, SCHEME_CKKS = 0, 1, 2
+
+_EXC = {1: ValueError, 2: RuntimeError, 3: IndexError, 4: RuntimeError, 5: MemoryError}
+
+
+class CatError(Exception):
+    pass
+
+
+def _check(status: int):
+    if status != 0:
+        msg = _lib.load().cat_last_error().decode()
+        # invalid_argument -> ValueError, logic_error -> RuntimeError, out_of_range -> IndexError
+        raise _EXC.get(status, CatError)(msg)
+
+
+def galois_elt_from_step(log_n: int, step: int) -> int:
+    elt = _lib.load().cat_galois_elt_from_step(log_n, step)
+    if elt == 0:
+        raise ValueError("step count too large")
+    return elt
+
+
+def to_device(a: np.ndarray, device="cuda:0") -> torch.Tensor:
+    assert a.dtype == np.uint64
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(device)
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().numpy().view(np.uint64)
+
+
+class Context:
+    """One context per device (cat_ctx_create).  primes = key-level chain, last = special prime."""
+
+    def __init__(self, log_n: int, primes, scheme: int = SCHEME_CKKS, plain_modulus: int = 0, device: int = 0):
+        self.lib = _lib.load()
+        self.log_n, self.n, self.k = log_n, 1 << log_n, len(primes)
+        self.primes = [int(p) for p in primes]
+        self.scheme = scheme
+        self.device = device
+        arr = (C.c_uint64 * len(primes))(*self.primes)
+        h = C.c_void_p()
+        _check(self.lib.cat_ctx_create(log_n, arr, len(primes), scheme, plain_modulus, device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cat_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers -------------------------------------------------------------------------------------
+    @staticmethod
+    def _p(t: torch.Tensor):
+        assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()
+        return C.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _ids(limb_ids):
+        if limb_ids is None:
+            return None
+        return (C.c_uint32 * len(limb_ids))(*[int(i) for i in limb_ids])
+
+    def root(self, i: int) -> int:
+        return int(self.lib.cat_ctx_root(self.h, i))
+
+    def moduli(self):
+        return [int(self.lib.cat_ctx_modulus(self.h, i)) for i in range(self.lib.cat_ctx_n_moduli(self.h))]
+
+    def reserve(self, nbytes: int):
+        _check(self.lib.cat_ctx_reserve(self.h, nbytes))
+
+    # -- a1/a2 -----------------------------------------------------------------------------------------
+    def ntt_forward(self, x: torch.Tensor, limb_ids=None, lazy=False):
+        """x: [..., n_limbs, N], in place."""
+        nl = x.shape[-2]
+        npoly = x.numel() // (nl * self.n)
+        _check(self.lib.cat_ntt_forward(self.h, self._p(x), self._ids(limb_ids), nl, npoly, int(lazy), self._stream()))
+        return x
+
+    def ntt_inverse(self, x: torch.Tensor, limb_ids=None, lazy=False):
+        nl = x.shape[-2]
+        npoly = x.numel() // (nl * self.n)
+        _check(self.lib.cat_ntt_inverse(self.h, self._p(x), self._ids(limb_ids), nl, npoly, int(lazy), self._stream()))
+        return x
+
+    # -- a4/a5/a6 ---------------------------------------------------------------------------------------
+    def _binary(self, fn, a, b, out, limb_ids):
+        out = torch.empty_like(a) if out is None else out
+        nl = a.shape[-2]
+        npoly = a.numel() // (nl * self.n)
+        _check(fn(self.h, self._p(a), self._p(b), self._p(out), self._ids(limb_ids), nl, npoly, self._stream()))
+        return out
+
+    def _unary(self, fn, a, out, limb_ids):
+        out = torch.empty_like(a) if out is None else out
+        nl = a.shape[-2]
+        npoly = a.numel() // (nl * self.n)
+        _check(fn(self.h, self._p(a), self._p(out), self._ids(limb_ids), nl, npoly, self._stream()))
+        return out
+
+    def _scalar(self, fn, a, scalars, out, limb_ids):
+        out = torch.empty_like(a) if out is None else out
+        nl = a.shape[-2]
+        npoly = a.numel() // (nl * self.n)
+        sc = (C.c_uint64 * nl)(*[int(s) for s in scalars])
+        _check(fn(self.h, self._p(a), sc, self._p(out), self._ids(limb_ids), nl, npoly, self._stream()))
+        return out
+
+    def add(self, a, b, out=None, limb_ids=None):
+        return self._binary(self.lib.cat_add, a, b, out, limb_ids)
+
+    def sub(self, a, b, out=None, limb_ids=None):
+        return self._binary(self.lib.cat_sub, a, b, out, limb_ids)
+
+    def dyadic(self, a, b, out=None, limb_ids=None):
+        return self._binary(self.lib.cat_dyadic, a, b, out, limb_ids)
+
+    def negate(self, a, out=None, limb_ids=None):
+        return self._unary(self.lib.cat_negate, a, out, limb_ids)
+
+    def modulo(self, a, out=None, limb_ids=None):
+        return self._unary(self.lib.cat_modulo, a, out, limb_ids)
+
+    def mul_scalar(self, a, scalars, out=None, limb_ids=None):
+        return self._scalar(self.lib.cat_mul_scalar, a, scalars, out, limb_ids)
+
+    def add_scalar(self, a, scalars, out=None, limb_ids=None):
+        return self._scalar(self.lib.cat_add_scalar, a, scalars, out, limb_ids)
+
+    def sub_scalar(self, a, scalars, out=None, limb_ids=None):
+        return self._scalar(self.lib.cat_sub_scalar, a, scalars, out, limb_ids)
+
+    # -- evaluator-level ----------------------------------------------------------------------------------
+    def ckks_multiply(self, x, y, out=None):
+        """x, y: [batch, 2, L, N] -> [batch, 3, L, N]"""
+        b, _, L, _ = x.shape
+        out = torch.empty((b, 3, L, self.n), dtype=torch.int64, device=x.device) if out is None else out
+        _check(self.lib.cat_ckks_multiply(self.h, self._p(x), self._p(y), self._p(out), L, b, self._stream()))
+        return out
+
+    def bfv_multiply(self, x, y, out=None):
+        b, _, L, _ = x.shape
+        out = torch.empty((b, 3, L, self.n), dtype=torch.int64, device=x.device) if out is None else out
+        _check(self.lib.cat_bfv_multiply(self.h, self._p(x), self._p(y), self._p(out), L, b, self._stream()))
+        return out
+
+    def switch_key(self, enc, target, key):
+        """enc: [batch, 2, L, N] in place; target: [batch, L, N]; key: [k-1, 2, k, N]"""
+        b, _, L, _ = enc.shape
+        _check(self.lib.cat_switch_key(self.h, self._p(enc), self._p(target), self._p(key), L, b, self._stream()))
+        return enc
+
+    def relinearize(self, ct3, key):
+        """ct3: [batch, 3, L, N]; returns a view of the first two polys (updated in place)."""
+        b, _, L, _ = ct3.shape
+        _check(self.lib.cat_relinearize(self.h, self._p(ct3), self._p(key), L, b, self._stream()))
+        return ct3[:, :2]
+
+    def rescale(self, ct, out=None):
+        b, size, L, _ = ct.shape
+        out = torch.empty((b, size, L - 1, self.n), dtype=torch.int64, device=ct.device) if out is None else out
+        _check(self.lib.cat_rescale(self.h, self._p(ct), self._p(out), L, size, b, self._stream()))
+        return out
+
+    def mod_drop(self, ct, out=None):
+        b, size, L, _ = ct.shape
+        out = torch.empty((b, size, L - 1, self.n), dtype=torch.int64, device=ct.device) if out is None else out
+        _check(self.lib.cat_mod_drop(self.h, self._p(ct), self._p(out), L, size, b, self._stream()))
+        return out
+
+    def apply_galois_ntt(self, x, elt, out=None):
+        out = torch.empty_like(x) if out is None else out
+        nl = x.shape[-2]
+        npoly = x.numel() // (nl * self.n)
+        _check(self.lib.cat_apply_galois_ntt(self.h, self._p(x), self._p(out), elt, nl, npoly, self._stream()))
+        return out
+
+    def apply_galois(self, x, elt, out=None, limb_ids=None):
+        out = torch.empty_like(x) if out is None else out
+        nl = x.shape[-2]
+        npoly = x.numel() // (nl * self.n)
+        _check(self.lib.cat_apply_galois(self.h, self._p(x), self._p(out), elt, self._ids(limb_ids), nl, npoly,
+                                         self._stream()))
+        return out
+
+    def apply_galois_inplace(self, ct, elt, key):
+        b, _, L, _ = ct.shape
+        _check(self.lib.cat_apply_galois_inplace(self.h, self._p(ct), elt, self._p(key), L, b, self._stream()))
+        return ct
+
+    def rotate_vector(self, ct, step, key):
+        return self.apply_galois_inplace(ct, galois_elt_from_step(self.log_n, step), key)

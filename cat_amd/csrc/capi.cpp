@@ -1,0 +1,661 @@
+// C ABI of libcat_amd.so (include/cat_amd.h): argument validation in the reference's terms, context
+// construction (table precompute + upload) and dispatch to the HIP kernels.
+#include "context.hpp"
+
+#include <cstring>
+#include <new>
+
+using namespace cat;
+
+namespace
+{
+    thread_local std::string g_last_error;
+}
+
+namespace cat
+{
+    void set_error(const std::string &msg)
+    {
+        g_last_error = msg;
+    }
+
+    cat_status fail(cat_status code, const std::string &msg)
+    {
+        g_last_error = msg;
+        return code;
+    }
+
+    cat_status hip_fail(hipError_t e, const char *what)
+    {
+        g_last_error = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+        return e == hipErrorOutOfMemory ? CAT_ERR_NOMEM : CAT_ERR_HIP;
+    }
+
+    void *workspace(cat_ctx *ctx, size_t bytes)
+    {
+        if (bytes <= ctx->ws_bytes)
+            return ctx->ws;
+        // earlier launches may still use the old block
+        if (hipDeviceSynchronize() != hipSuccess)
+        {
+            set_error("HIP error while growing the workspace");
+            return nullptr;
+        }
+        if (ctx->ws)
+            (void)hipFree(ctx->ws);
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+        size_t want = bytes + bytes / 8;
+        void *p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess)
+        {
+            want = bytes;
+            if (hipMalloc(&p, want) != hipSuccess)
+            {
+                set_error("out of device memory for the workspace");
+                return nullptr;
+            }
+        }
+        ctx->ws = p;
+        ctx->ws_bytes = want;
+        return p;
+    }
+
+    cat_status make_map(const cat_ctx *ctx, const uint32_t *limb_ids, uint32_t n_limbs, LimbMap &out)
+    {
+        if (n_limbs > CAT_MAX_MODULI)
+            return fail(CAT_ERR_INVALID_ARG, "too many limbs");
+        std::memset(&out, 0, sizeof(out));
+        for (uint32_t j = 0; j < n_limbs; ++j)
+        {
+            const uint32_t id = limb_ids ? limb_ids[j] : j;
+            if (id >= ctx->n_mod)
+                return fail(CAT_ERR_OUT_OF_RANGE, "limb_ids");
+            out.id[j] = (unsigned char)id;
+        }
+        return CAT_OK;
+    }
+
+    cat_status build_bfv_levels(cat_ctx *ctx); // bfv.hip
+    void destroy_bfv_levels(cat_ctx *ctx);
+} // namespace cat
+
+namespace
+{
+    cat_status check(cat_ctx *ctx)
+    {
+        if (!ctx)
+            return fail(CAT_ERR_INVALID_ARG, "ctx");
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess)
+            return hip_fail(e, "hipSetDevice");
+        return CAT_OK;
+    }
+
+    template <typename T>
+    cat_status upload_vec(T **dptr, const std::vector<T> &v)
+    {
+        CAT_HIP(hipMalloc((void **)dptr, v.size() * sizeof(T)));
+        CAT_HIP(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return CAT_OK;
+    }
+} // namespace
+
+extern "C" {
+
+const char *cat_version(void)
+{
+    return "cat_amd 0.1 (gfx950)";
+}
+
+const char *cat_last_error(void)
+{
+    return g_last_error.c_str();
+}
+
+cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_primes, int scheme,
+                          uint64_t plain_modulus, int device, cat_ctx **out)
+{
+    if (!out)
+        return fail(CAT_ERR_INVALID_ARG, "out");
+    *out = nullptr;
+    if (log_n < CAT_MIN_LOG_N || log_n > CAT_MAX_LOG_N)
+        return fail(CAT_ERR_INVALID_ARG, "poly_modulus_degree is invalid");
+    if (!primes || n_primes == 0 || n_primes > CAT_MAX_MODULI)
+        return fail(CAT_ERR_INVALID_ARG, "coeff_modulus is invalid");
+    if (scheme != CAT_SCHEME_NONE && scheme != CAT_SCHEME_BFV && scheme != CAT_SCHEME_CKKS)
+        return fail(CAT_ERR_INVALID_ARG, "unsupported scheme");
+    const size_t n = size_t(1) << log_n;
+    for (uint32_t i = 0; i < n_primes; ++i)
+    {
+        const uint64_t q = primes[i];
+        if (q < 2 || (q >> 61) != 0)
+            return fail(CAT_ERR_INVALID_ARG, "value can be at most 61-bit and cannot be 1");
+        if ((q - 1) % (2 * n) != 0 || !is_prime_u64(q))
+            return fail(CAT_ERR_INVALID_ARG, "invalid modulus");
+        for (uint32_t j = 0; j < i; ++j)
+            if (primes[j] == q)
+                return fail(CAT_ERR_INVALID_ARG, "coeff_modulus is invalid");
+    }
+    if (scheme == CAT_SCHEME_BFV && (plain_modulus < 2 || (plain_modulus >> 60) != 0))
+        return fail(CAT_ERR_INVALID_ARG, "plain_modulus is invalid");
+    CAT_HIP(hipSetDevice(device));
+
+    cat_ctx *ctx = new (std::nothrow) cat_ctx();
+    if (!ctx)
+        return fail(CAT_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+    ctx->log_n = log_n;
+    ctx->n = n;
+    ctx->k = n_primes;
+    ctx->scheme = scheme;
+    ctx->plain_modulus = plain_modulus;
+    std::vector<uint64_t> all(primes, primes + n_primes);
+    try
+    {
+        if (scheme == CAT_SCHEME_BFV)
+        {
+            // auxiliary 61-bit primes of the BEHZ bases (util/rns.cpp:625-635): m_sk, gamma, B_0 ...
+            // the largest level needs |B| <= k + 1 primes
+            std::vector<u64> aux = primes_descending(2 * n, 61, n_primes + 3);
+            for (u64 a : aux)
+                all.push_back(a);
+            if (all.size() > CAT_MAX_MODULI)
+                throw std::invalid_argument("coeff_modulus is invalid");
+        }
+        ctx->n_mod = (uint32_t)all.size();
+        std::vector<DevMod> dm(ctx->n_mod);
+        std::vector<MulOp> fwd(ctx->n_mod * n), inv(ctx->n_mod * n);
+        for (uint32_t i = 0; i < ctx->n_mod; ++i)
+        {
+            HostMod hm(all[i]);
+            HostNttTables t = build_ntt_tables((int)log_n, hm);
+            ctx->hmods.push_back(hm);
+            ctx->roots.push_back(t.root);
+            dm[i].q = hm.q;
+            dm[i].ratio0 = hm.ratio0;
+            dm[i].ratio1 = hm.ratio1;
+            dm[i].inv_n_op = t.inv_n;
+            dm[i].inv_n_quo = hm.shoup(t.inv_n);
+            dm[i].inv_n_w_op = t.inv_n_w;
+            dm[i].inv_n_w_quo = hm.shoup(t.inv_n_w);
+            dm[i].pad = 0;
+            std::memcpy(&fwd[i * n], t.fwd.data(), n * sizeof(MulOp));
+            std::memcpy(&inv[i * n], t.inv.data(), n * sizeof(MulOp));
+        }
+        const uint32_t k = ctx->k;
+        ctx->h_inv_mod.assign((size_t)k * k, MulOp{ 0, 0 });
+        ctx->h_half_mod.assign((size_t)k * k, 0);
+        for (uint32_t a = 0; a < k; ++a)
+            for (uint32_t b = 0; b < k; ++b)
+            {
+                if (a == b)
+                    continue;
+                const HostMod &mb = ctx->hmods[b];
+                u64 iv = 0;
+                if (!invert_mod(ctx->hmods[a].q % mb.q, mb.q, iv))
+                    throw std::logic_error("invalid rns bases");
+                ctx->h_inv_mod[(size_t)a * k + b] = MulOp{ iv, mb.shoup(iv) };
+                ctx->h_half_mod[(size_t)a * k + b] = (ctx->hmods[a].q >> 1) % mb.q;
+            }
+        cat_status st = upload_vec(&ctx->d_mods, dm);
+        if (st == CAT_OK)
+            st = upload_vec(&ctx->d_tw_fwd, fwd);
+        if (st == CAT_OK)
+            st = upload_vec(&ctx->d_tw_inv, inv);
+        if (st == CAT_OK)
+            st = upload_vec(&ctx->d_inv_mod, ctx->h_inv_mod);
+        if (st == CAT_OK)
+            st = upload_vec(&ctx->d_half_mod, ctx->h_half_mod);
+        if (st == CAT_OK && scheme == CAT_SCHEME_BFV)
+            st = build_bfv_levels(ctx);
+        if (st != CAT_OK)
+        {
+            cat_ctx_destroy(ctx);
+            return st;
+        }
+    }
+    catch (const std::invalid_argument &e)
+    {
+        cat_ctx_destroy(ctx);
+        return fail(CAT_ERR_INVALID_ARG, e.what());
+    }
+    catch (const std::logic_error &e)
+    {
+        cat_ctx_destroy(ctx);
+        return fail(CAT_ERR_LOGIC, e.what());
+    }
+    catch (const std::bad_alloc &)
+    {
+        cat_ctx_destroy(ctx);
+        return fail(CAT_ERR_NOMEM, "out of host memory");
+    }
+    *out = ctx;
+    return CAT_OK;
+}
+
+cat_status cat_ctx_destroy(cat_ctx *ctx)
+{
+    if (!ctx)
+        return CAT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    destroy_bfv_levels(ctx);
+    if (ctx->d_mods) (void)hipFree(ctx->d_mods);
+    if (ctx->d_tw_fwd) (void)hipFree(ctx->d_tw_fwd);
+    if (ctx->d_tw_inv) (void)hipFree(ctx->d_tw_inv);
+    if (ctx->d_inv_mod) (void)hipFree(ctx->d_inv_mod);
+    if (ctx->d_half_mod) (void)hipFree(ctx->d_half_mod);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    delete ctx;
+    return CAT_OK;
+}
+
+cat_status cat_ctx_reserve(cat_ctx *ctx, size_t bytes)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    return workspace(ctx, bytes) || bytes == 0 ? CAT_OK : CAT_ERR_NOMEM;
+}
+
+size_t cat_ctx_workspace_bytes(const cat_ctx *ctx)
+{
+    return ctx ? ctx->ws_bytes : 0;
+}
+
+uint32_t cat_ctx_log_n(const cat_ctx *ctx)
+{
+    return ctx ? ctx->log_n : 0;
+}
+
+uint32_t cat_ctx_n_primes(const cat_ctx *ctx)
+{
+    return ctx ? ctx->k : 0;
+}
+
+uint64_t cat_ctx_root(const cat_ctx *ctx, uint32_t i)
+{
+    return ctx && i < ctx->n_mod ? ctx->roots[i] : 0;
+}
+
+uint32_t cat_ctx_n_moduli(const cat_ctx *ctx)
+{
+    return ctx ? ctx->n_mod : 0;
+}
+
+uint64_t cat_ctx_modulus(const cat_ctx *ctx, uint32_t i)
+{
+    return ctx && i < ctx->n_mod ? ctx->hmods[i].q : 0;
+}
+
+cat_status cat_malloc(cat_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if (!d_ptr)
+        return fail(CAT_ERR_INVALID_ARG, "d_ptr");
+    CAT_HIP(hipMalloc(d_ptr, bytes ? bytes : 8));
+    return CAT_OK;
+}
+
+cat_status cat_free(cat_ctx *ctx, void *d_ptr)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    CAT_HIP(hipFree(d_ptr));
+    return CAT_OK;
+}
+
+cat_status cat_upload(cat_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    CAT_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+    return CAT_OK;
+}
+
+cat_status cat_download(cat_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    CAT_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
+    return CAT_OK;
+}
+
+cat_status cat_stream_sync(cat_ctx *ctx, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    CAT_HIP(hipStreamSynchronize((hipStream_t)s));
+    return CAT_OK;
+}
+
+static cat_status ntt_common(cat_ctx *ctx, bool fwd, uint64_t *d_data, const uint32_t *limb_ids, uint32_t n_limbs,
+                             uint32_t n_polys, int lazy, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if (!d_data && n_limbs && n_polys)
+        return fail(CAT_ERR_INVALID_ARG, "operand");
+    LimbMap map;
+    st = make_map(ctx, limb_ids, n_limbs, map);
+    if (st != CAT_OK)
+        return st;
+    return launch_ntt(ctx, fwd, (u64 *)d_data, map, n_limbs, n_polys, lazy != 0, (hipStream_t)s);
+}
+
+cat_status cat_ntt_forward(cat_ctx *ctx, uint64_t *d_data, const uint32_t *limb_ids, uint32_t n_limbs,
+                           uint32_t n_polys, int lazy, cat_stream s)
+{
+    return ntt_common(ctx, true, d_data, limb_ids, n_limbs, n_polys, lazy, s);
+}
+
+cat_status cat_ntt_inverse(cat_ctx *ctx, uint64_t *d_data, const uint32_t *limb_ids, uint32_t n_limbs,
+                           uint32_t n_polys, int lazy, cat_stream s)
+{
+    return ntt_common(ctx, false, d_data, limb_ids, n_limbs, n_polys, lazy, s);
+}
+
+static cat_status ew_common(cat_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, uint64_t *out,
+                            const uint32_t *limb_ids, uint32_t n_limbs, uint32_t n_polys, cat_stream s, bool binary)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if (n_limbs && n_polys)
+    {
+        if (!a)
+            return fail(CAT_ERR_INVALID_ARG, binary ? "operand1" : "poly");
+        if (binary && !b)
+            return fail(CAT_ERR_INVALID_ARG, "operand2");
+        if (!out)
+            return fail(CAT_ERR_INVALID_ARG, "result");
+    }
+    LimbMap map;
+    st = make_map(ctx, limb_ids, n_limbs, map);
+    if (st != CAT_OK)
+        return st;
+    return launch_ew(ctx, op, (const u64 *)a, (const u64 *)b, (u64 *)out, map, n_limbs, n_polys, (hipStream_t)s);
+}
+
+cat_status cat_add(cat_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, const uint32_t *ids, uint32_t nl,
+                   uint32_t np, cat_stream s)
+{
+    return ew_common(ctx, EW_ADD, a, b, out, ids, nl, np, s, true);
+}
+
+cat_status cat_sub(cat_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, const uint32_t *ids, uint32_t nl,
+                   uint32_t np, cat_stream s)
+{
+    return ew_common(ctx, EW_SUB, a, b, out, ids, nl, np, s, true);
+}
+
+cat_status cat_negate(cat_ctx *ctx, const uint64_t *a, uint64_t *out, const uint32_t *ids, uint32_t nl, uint32_t np,
+                      cat_stream s)
+{
+    return ew_common(ctx, EW_NEG, a, nullptr, out, ids, nl, np, s, false);
+}
+
+cat_status cat_dyadic(cat_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, const uint32_t *ids,
+                      uint32_t nl, uint32_t np, cat_stream s)
+{
+    return ew_common(ctx, EW_DYADIC, a, b, out, ids, nl, np, s, true);
+}
+
+cat_status cat_modulo(cat_ctx *ctx, const uint64_t *a, uint64_t *out, const uint32_t *ids, uint32_t nl, uint32_t np,
+                      cat_stream s)
+{
+    return ew_common(ctx, EW_MODULO, a, nullptr, out, ids, nl, np, s, false);
+}
+
+static cat_status scalar_common(cat_ctx *ctx, int op, const uint64_t *a, const uint64_t *scalars, uint64_t *out,
+                                const uint32_t *ids, uint32_t nl, uint32_t np, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if (nl && np && (!a || !out))
+        return fail(CAT_ERR_INVALID_ARG, a ? "result" : "poly");
+    if (nl && !scalars)
+        return fail(CAT_ERR_INVALID_ARG, "scalar");
+    LimbMap map;
+    st = make_map(ctx, ids, nl, map);
+    if (st != CAT_OK)
+        return st;
+    return launch_scalar(ctx, op, (const u64 *)a, (const u64 *)scalars, (u64 *)out, map, nl, np, (hipStream_t)s);
+}
+
+cat_status cat_mul_scalar(cat_ctx *ctx, const uint64_t *a, const uint64_t *sc, uint64_t *out, const uint32_t *ids,
+                          uint32_t nl, uint32_t np, cat_stream s)
+{
+    return scalar_common(ctx, SCALAR_MUL, a, sc, out, ids, nl, np, s);
+}
+
+cat_status cat_add_scalar(cat_ctx *ctx, const uint64_t *a, const uint64_t *sc, uint64_t *out, const uint32_t *ids,
+                          uint32_t nl, uint32_t np, cat_stream s)
+{
+    return scalar_common(ctx, SCALAR_ADD, a, sc, out, ids, nl, np, s);
+}
+
+cat_status cat_sub_scalar(cat_ctx *ctx, const uint64_t *a, const uint64_t *sc, uint64_t *out, const uint32_t *ids,
+                          uint32_t nl, uint32_t np, cat_stream s)
+{
+    return scalar_common(ctx, SCALAR_SUB, a, sc, out, ids, nl, np, s);
+}
+
+static cat_status level_check(cat_ctx *ctx, uint32_t L, bool needs_next)
+{
+    // a level with L limbs uses primes 0..L-1; data levels have L <= k-1 when k > 1 (context.cu:607-637)
+    if (L == 0 || L > ctx->k)
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (needs_next && L < 2)
+        return fail(CAT_ERR_INVALID_ARG, "end of modulus switching chain reached");
+    return CAT_OK;
+}
+
+cat_status cat_ckks_multiply(cat_ctx *ctx, const uint64_t *x, const uint64_t *y, uint64_t *out, uint32_t L,
+                             uint32_t batch, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if ((st = level_check(ctx, L, false)) != CAT_OK)
+        return st;
+    if (batch && (!x || !y || !out))
+        return fail(CAT_ERR_INVALID_ARG, "encrypted1 or encrypted2 is not valid");
+    if (out == x || out == y)
+        return fail(CAT_ERR_INVALID_ARG, "destination must not alias the inputs");
+    return launch_ckks_tensor(ctx, (const u64 *)x, (const u64 *)y, (u64 *)out, L, batch, (hipStream_t)s);
+}
+
+cat_status cat_switch_key(cat_ctx *ctx, uint64_t *enc, const uint64_t *target, const uint64_t *key, uint32_t L,
+                          uint32_t batch, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if (ctx->scheme == CAT_SCHEME_NONE || ctx->k < 2)
+        return fail(CAT_ERR_LOGIC, "keyswitching is not supported by the context");
+    if (L == 0 || L >= ctx->k)
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (!target)
+        return fail(CAT_ERR_INVALID_ARG, "target_iter");
+    if (!enc)
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (!key)
+        return fail(CAT_ERR_INVALID_ARG, "kswitch_keys is not valid for encryption parameters");
+    if (L >= 256)
+        return fail(CAT_ERR_LOGIC, "invalid parameters");
+    if (batch == 0)
+        return CAT_OK;
+    return launch_switch_key(ctx, (u64 *)enc, (const u64 *)target, (const u64 *)key, L, batch, (size_t)2 * L * ctx->n,
+                             (size_t)L * ctx->n, (hipStream_t)s);
+}
+
+cat_status cat_relinearize(cat_ctx *ctx, uint64_t *ct3, const uint64_t *key, uint32_t L, uint32_t batch, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if (!key)
+        return fail(CAT_ERR_INVALID_ARG, "relin_keys is not valid for encryption parameters");
+    if (!ct3)
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (ctx->scheme == CAT_SCHEME_NONE || ctx->k < 2)
+        return fail(CAT_ERR_LOGIC, "keyswitching is not supported by the context");
+    if (L == 0 || L >= ctx->k || L >= 256)
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (batch == 0)
+        return CAT_OK;
+    // the target of ciphertext b is its own third polynomial (stride 3*L*N for both)
+    const size_t stride = (size_t)3 * L * ctx->n;
+    return launch_switch_key(ctx, (u64 *)ct3, (const u64 *)ct3 + (size_t)2 * L * ctx->n, (const u64 *)key, L, batch,
+                             stride, stride, (hipStream_t)s);
+}
+
+cat_status cat_rescale(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t L, uint32_t size, uint32_t batch,
+                       cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if ((st = level_check(ctx, L, true)) != CAT_OK)
+        return st;
+    if (size * batch && (!in || !out))
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    return launch_rescale(ctx, (const u64 *)in, (u64 *)out, L, size, batch, (hipStream_t)s);
+}
+
+cat_status cat_mod_drop(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t L, uint32_t size, uint32_t batch,
+                        cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if ((st = level_check(ctx, L, true)) != CAT_OK)
+        return st;
+    const uint32_t polys = size * batch;
+    if (polys && (!in || !out))
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (in == out && polys > 1)
+    {
+        const size_t bytes = (size_t)polys * (L - 1) * ctx->n * sizeof(u64);
+        u64 *ws = (u64 *)workspace(ctx, bytes);
+        if (!ws)
+            return CAT_ERR_NOMEM;
+        st = launch_drop_limb(ctx, (const u64 *)in, ws, L, polys, (hipStream_t)s);
+        if (st != CAT_OK)
+            return st;
+        CAT_HIP(hipMemcpyAsync(out, ws, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+        return CAT_OK;
+    }
+    if (in == out)
+        return CAT_OK;
+    return launch_drop_limb(ctx, (const u64 *)in, (u64 *)out, L, polys, (hipStream_t)s);
+}
+
+uint32_t cat_galois_elt_from_step(uint32_t log_n, int step)
+{
+    const uint32_t n = 1u << log_n;
+    const uint64_t m = 2ull * n;
+    if (step == 0)
+        return (uint32_t)(m - 1);
+    const bool neg = step < 0;
+    const uint32_t pos = (uint32_t)(neg ? -(int64_t)step : step);
+    if (pos >= (n >> 1))
+        return 0;
+    uint32_t e = neg ? (n >> 1) - pos : pos;
+    uint64_t elt = 1;
+    while (e--)
+        elt = (elt * 3) & (m - 1);
+    return (uint32_t)elt;
+}
+
+static cat_status galois_check(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t elt)
+{
+    if (!in)
+        return fail(CAT_ERR_INVALID_ARG, "operand");
+    if (!out)
+        return fail(CAT_ERR_INVALID_ARG, "result");
+    if (in == out)
+        return fail(CAT_ERR_INVALID_ARG, "result cannot point to the same value as operand");
+    if (!(elt & 1) || elt >= 2 * (uint64_t)ctx->n)
+        return fail(CAT_ERR_INVALID_ARG, "Galois element is not valid");
+    return CAT_OK;
+}
+
+cat_status cat_apply_galois_ntt(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t elt, uint32_t nl,
+                                uint32_t np, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if ((st = galois_check(ctx, in, out, elt)) != CAT_OK)
+        return st;
+    return launch_galois(ctx, true, (const u64 *)in, (u64 *)out, elt, ctx->identity_map(), nl ? nl : 1, nl ? np : 0,
+                         (hipStream_t)s);
+}
+
+cat_status cat_apply_galois(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t elt, const uint32_t *ids,
+                            uint32_t nl, uint32_t np, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if ((st = galois_check(ctx, in, out, elt)) != CAT_OK)
+        return st;
+    LimbMap map;
+    st = make_map(ctx, ids, nl, map);
+    if (st != CAT_OK)
+        return st;
+    return launch_galois(ctx, false, (const u64 *)in, (u64 *)out, elt, map, nl ? nl : 1, nl ? np : 0, (hipStream_t)s);
+}
+
+cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, const uint64_t *key, uint32_t L,
+                                    uint32_t batch, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if (ctx->scheme == CAT_SCHEME_NONE || ctx->k < 2)
+        return fail(CAT_ERR_LOGIC, "keyswitching is not supported by the context");
+    if (!ct || L == 0 || L >= ctx->k)
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (!key)
+        return fail(CAT_ERR_INVALID_ARG, "Galois key not present");
+    if (!(elt & 1) || elt >= 2 * (uint64_t)ctx->n)
+        return fail(CAT_ERR_INVALID_ARG, "Galois element is not valid");
+    if (batch == 0)
+        return CAT_OK;
+    // temp layout: [batch][2][L][N] permuted copy; c0 <- perm(c0), target <- perm(c1), c1 <- 0 (:2410-2449).
+    // The permuted copy lives in a caller-invisible buffer that must survive launch_switch_key's own
+    // workspace use, so it is carved from the same workspace block, after the key-switch region.
+    const size_t N = ctx->n, ctw = (size_t)2 * L * N;
+    const size_t ks_words = (size_t)batch * ((size_t)L + (size_t)(L + 1) * L + 2 * (L + 1) + 2 * L) * N;
+    u64 *ws = (u64 *)workspace(ctx, (ks_words + (size_t)batch * (ctw + L * N)) * sizeof(u64));
+    if (!ws)
+        return CAT_ERR_NOMEM;
+    u64 *perm = ws + ks_words, *tgt = perm + (size_t)batch * ctw;
+    const bool ntt = ctx->scheme == CAT_SCHEME_CKKS;
+    st = launch_galois(ctx, ntt, (const u64 *)ct, perm, elt, ctx->identity_map(), L, batch * 2, (hipStream_t)s);
+    if (st != CAT_OK)
+        return st;
+    for (uint32_t b = 0; b < batch; ++b)
+    {
+        u64 *c = (u64 *)ct + b * ctw;
+        CAT_HIP(hipMemcpyAsync(c, perm + b * ctw, L * N * sizeof(u64), hipMemcpyDeviceToDevice, (hipStream_t)s));
+        CAT_HIP(hipMemcpyAsync(tgt + (size_t)b * L * N, perm + b * ctw + L * N, L * N * sizeof(u64),
+                               hipMemcpyDeviceToDevice, (hipStream_t)s));
+        CAT_HIP(hipMemsetAsync(c + L * N, 0, L * N * sizeof(u64), (hipStream_t)s));
+    }
+    return launch_switch_key(ctx, (u64 *)ct, tgt, (const u64 *)key, L, batch, ctw, (size_t)L * N, (hipStream_t)s);
+}
+
+} // extern "C"

@@ -1,0 +1,116 @@
+// Internal context shared by the C-ABI translation units (not installed).
+#pragma once
+#include "../../include/cat_amd.h"
+#include "host_math.hpp"
+#include "modarith.cuh"
+
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+namespace cat
+{
+    // BEHZ tool of one level (util/rns.cpp:578-787), device-resident constants.
+    struct BfvLevel
+    {
+        bool ready = false;
+        uint32_t L = 0, B = 0, Bsk = 0; // |q|, |B|, |Bsk| = B + 1
+        LimbMap map_q{}, map_Bsk{};     // modulus indices
+        uint32_t idx_msk = 0;
+        // device arrays (u64 unless noted)
+        u64 *d_blob = nullptr;
+        // offsets into d_blob (in words)
+        size_t o_inv_punc_q = 0;   // [L] MulOp: (q/q_i)^-1 mod q_i
+        size_t o_mtilde_q = 0;     // [L] MulOp: m_tilde mod q_i
+        size_t o_q_to_Bsk = 0;     // [Bsk][L]: (q/q_i) mod Bsk_o
+        size_t o_q_to_mt = 0;      // [L]: (q/q_i) mod m_tilde
+        size_t o_inv_punc_B = 0;   // [B] MulOp: (B/b_i)^-1 mod b_i
+        size_t o_B_to_q = 0;       // [L][B]: (B/b_i) mod q_o
+        size_t o_B_to_msk = 0;     // [B]: (B/b_i) mod m_sk
+        size_t o_prod_q_Bsk = 0;   // [Bsk] MulOp: q mod Bsk_i
+        size_t o_inv_mt_Bsk = 0;   // [Bsk] MulOp: m_tilde^-1 mod Bsk_i
+        size_t o_inv_q_Bsk = 0;    // [Bsk] MulOp: q^-1 mod Bsk_i
+        size_t o_prodB_q = 0;      // [L] MulOp: B mod q_i
+        size_t o_negprodB_q = 0;   // [L] MulOp: -B mod q_i
+        size_t o_t_q = 0;          // [L] MulOp: t mod q_i
+        size_t o_t_Bsk = 0;        // [Bsk] MulOp: t mod Bsk_i
+        u64 neg_inv_q_mt = 0;      // -q^-1 mod m_tilde
+        MulOp inv_B_msk{};         // B^-1 mod m_sk
+    };
+} // namespace cat
+
+struct cat_ctx
+{
+    int device = 0;
+    uint32_t log_n = 0;
+    size_t n = 0;
+    uint32_t k = 0;     // coefficient primes (key level)
+    uint32_t n_mod = 0; // k + BFV auxiliary primes
+    int scheme = 0;
+    cat::u64 plain_modulus = 0;
+    std::vector<cat::HostMod> hmods;
+    std::vector<cat::u64> roots;
+
+    DevMod *d_mods = nullptr;
+    MulOp *d_tw_fwd = nullptr; // [n_mod][n]
+    MulOp *d_tw_inv = nullptr; // [n_mod][n]
+    MulOp *d_inv_mod = nullptr; // [k][k]: entry [a][b] = q_a^-1 mod q_b
+    std::vector<MulOp> h_inv_mod;
+    cat::u64 *d_half_mod = nullptr; // [k][k]: entry [a][b] = (q_a >> 1) mod q_b
+    std::vector<cat::u64> h_half_mod;
+
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+
+    std::vector<cat::BfvLevel> bfv; // index L
+
+    LimbMap identity_map() const
+    {
+        LimbMap m{};
+        for (int i = 0; i < 64; ++i)
+            m.id[i] = (unsigned char)i;
+        return m;
+    }
+};
+
+namespace cat
+{
+    void set_error(const std::string &msg);
+    cat_status fail(cat_status code, const std::string &msg);
+    cat_status hip_fail(hipError_t e, const char *what);
+    // Grows the context workspace to at least `bytes`; returns nullptr (and sets the error) on failure.
+    void *workspace(cat_ctx *ctx, size_t bytes);
+    cat_status make_map(const cat_ctx *ctx, const uint32_t *limb_ids, uint32_t n_limbs, LimbMap &out);
+
+    // ---- kernel launchers (ntt.hip, polyops.hip, keyswitch.hip, bfv.hip) ----
+    cat_status launch_ntt(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
+                          uint32_t n_polys, bool lazy, hipStream_t s);
+    // general form: objects `poly_stride` words apart; limb j uses modulus map.id[j / limb_group];
+    // skip_diag skips limbs with j % limb_group == j / limb_group (key switching's I == J operands)
+    cat_status launch_ntt_ex(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
+                             uint32_t n_polys, bool lazy, u64 poly_stride, uint32_t limb_group, bool skip_diag,
+                             hipStream_t s);
+    cat_status launch_ew(cat_ctx *ctx, int op, const u64 *a, const u64 *b, u64 *out, const LimbMap &map,
+                         uint32_t n_limbs, uint32_t n_polys, hipStream_t s);
+    cat_status launch_scalar(cat_ctx *ctx, int op, const u64 *a, const u64 *scalars, u64 *out, const LimbMap &map,
+                             uint32_t n_limbs, uint32_t n_polys, hipStream_t s);
+    cat_status launch_ckks_tensor(cat_ctx *ctx, const u64 *x, const u64 *y, u64 *out, uint32_t L, uint32_t batch,
+                                  hipStream_t s);
+    cat_status launch_galois(cat_ctx *ctx, bool ntt_domain, const u64 *in, u64 *out, uint32_t elt, const LimbMap &map,
+                             uint32_t n_limbs, uint32_t n_polys, hipStream_t s);
+    cat_status launch_drop_limb(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t n_polys, hipStream_t s);
+    // enc_stride / target_stride: words between consecutive ciphertexts / targets of the batch
+    cat_status launch_switch_key(cat_ctx *ctx, u64 *enc, const u64 *target, const u64 *key, uint32_t L, uint32_t batch,
+                                 size_t enc_stride, size_t target_stride, hipStream_t s);
+    cat_status launch_rescale(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t size, uint32_t batch,
+                              hipStream_t s);
+    enum { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_DYADIC = 3, EW_MODULO = 4, SCALAR_MUL = 0, SCALAR_ADD = 1, SCALAR_SUB = 2 };
+} // namespace cat
+
+#define CAT_HIP(call)                                        \
+    do                                                       \
+    {                                                        \
+        hipError_t e__ = (call);                             \
+        if (e__ != hipSuccess)                               \
+            return cat::hip_fail(e__, #call);                \
+    } while (0)

@@ -1,0 +1,447 @@
+// Key switching (Evaluator::switch_key_inplace, evaluator.cpp:2523-2820, CKKS + BFV branches) and
+// rescale / BFV mod-switch (RNSTool::divide_and_round_q_last[_ntt]_inplace, util/rns.cpp:789-901).
+//
+// Notation as in the reference: d = decomp_modulus_size (= L), k = key_modulus_size, special prime
+// P = q_{k-1}, key_index(I) = I < d ? I : k-1.
+//
+//  step 1  t_target <- target (CKKS: inverse NTT, canonical)                         :2604-2611
+//  step 2  raise: ext[I][J] = t_target[J] mod q_key_index(I)   (copy when q_J <= q)  :2643-2651
+//          forward lazy NTT of every ext[I][J] except CKKS I == J (original limb)    :2635-2654
+//  step 3  inner product with the key in 128-bit accumulators, one Barrett-128       :2658-2708
+//  step 4  mod-down: INTT_P(t_last), +P/2, Barrett-64; per limb: reduce, +fix,
+//          NTT (CKKS) / INTT of the product (BFV), subtract, * P^-1, add to ct       :2759-2818
+#include "context.hpp"
+
+namespace
+{
+    struct RaiseArgs
+    {
+        const u64 *t_target; // [batch][d][N] coefficient form, canonical
+        u64 *ext;            // [batch][d+1][d][N]
+        const DevMod *mods;
+        u32 d, k, log_n;
+        int skip_diag;
+        u64 src_stride2; // vectors between consecutive t_target objects
+        u64 total2;      // batch*(d+1)*d*N/2
+    };
+
+    __global__ __launch_bounds__(256) void ks_raise_kernel(RaiseArgs g)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1);
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            u64 r = i >> (g.log_n - 1);
+            const u32 J = (u32)(r % g.d);
+            r /= g.d;
+            const u32 I = (u32)(r % (g.d + 1));
+            const u64 b = r / (g.d + 1);
+            if (g.skip_diag && I == J)
+                continue;
+            const u32 ki = I == g.d ? g.k - 1 : I;
+            const DevMod m = g.mods[ki];
+            const u64 qJ = g.mods[J].q;
+            ulonglong2 v = reinterpret_cast<const ulonglong2 *>(g.t_target)[b * g.src_stride2 + ((u64)J << (g.log_n - 1)) + c];
+            if (qJ > m.q)
+            {
+                v.x = barrett64(v.x, m.q, m.ratio1);
+                v.y = barrett64(v.y, m.q, m.ratio1);
+            }
+            reinterpret_cast<ulonglong2 *>(g.ext)[i] = v;
+        }
+    }
+
+    struct MacArgs
+    {
+        const u64 *ext;    // [batch][d+1][d][N]
+        const u64 *target; // [batch][d][N] original (NTT form) for CKKS I == J
+        const u64 *key;    // [k-1][2][k][N]
+        u64 *prod;         // [batch][2][d+1][N]
+        const DevMod *mods;
+        u32 d, k, log_n;
+        int use_diag;
+        u64 target_stride; // words between consecutive target objects
+        u64 total;         // batch*(d+1)*N
+    };
+
+    // one thread per (b, I, coefficient); both key components share the operand reads
+    __global__ __launch_bounds__(256) void ks_mac_kernel(MacArgs g)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n = 1u << g.log_n;
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total; i += stride)
+        {
+            const u32 c = (u32)(i & (n - 1));
+            const u64 r = i >> g.log_n;
+            const u32 I = (u32)(r % (g.d + 1));
+            const u64 b = r / (g.d + 1);
+            const u32 ki = I == g.d ? g.k - 1 : I;
+            const DevMod m = g.mods[ki];
+            u64 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+            const u64 *e = g.ext + (((b * (g.d + 1) + I) * g.d) << g.log_n) + c;
+            const u64 *kp = g.key + ((u64)ki << g.log_n) + c;
+            for (u32 J = 0; J < g.d; ++J)
+            {
+                u64 x;
+                if (g.use_diag && I == J)
+                    x = g.target[b * g.target_stride + ((u64)J << g.log_n) + c];
+                else
+                    x = e[(u64)J << g.log_n];
+                const u64 k0 = kp[((u64)(J * 2 + 0) * g.k) << g.log_n];
+                const u64 k1 = kp[((u64)(J * 2 + 1) * g.k) << g.log_n];
+                mac128(lo0, hi0, x, k0);
+                mac128(lo1, hi1, x, k1);
+            }
+            // d < 256: the reference's lazy counter never triggers an intermediate reduction (:2619-2707)
+            u64 *o = g.prod + (((b * 2) * (g.d + 1) + I) << g.log_n) + c;
+            o[0] = barrett128(lo0, hi0, m.q, m.ratio0, m.ratio1);
+            o[(u64)(g.d + 1) << g.log_n] = barrett128(lo1, hi1, m.q, m.ratio0, m.ratio1);
+        }
+    }
+
+    struct DownArgs
+    {
+        u64 *prod;      // [batch][2][d+1][N]; limb d holds INTT_P (lazy) of the special-prime product
+        u64 *tmp;       // [batch][2][d][N]
+        u64 *enc;       // [batch][2][d][N]
+        const DevMod *mods;
+        const MulOp *inv_mod; // [k][k]
+        const u64 *half_mod;  // [k][k]
+        u32 d, k, log_n;
+        int lazy_shift;  // qi_lazy = q << lazy_shift (2 for CKKS, 1 for BFV)
+        u64 enc_stride2; // vectors between consecutive ciphertexts in enc
+        u64 total2;      // batch*2*d*N/2
+    };
+
+    // tmp[b][comp][j] = ((t_last + P/2 mod P) mod q_j) + (q_j - (P/2 mod q_j))          :2766-2789
+    __global__ __launch_bounds__(256) void ks_down_prepare_kernel(DownArgs g)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1);
+        const DevMod P = g.mods[g.k - 1];
+        const u64 half = P.q >> 1;
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 r = i >> (g.log_n - 1);
+            const u32 j = (u32)(r % g.d);
+            const u64 bc = r / g.d; // b*2 + comp
+            const DevMod m = g.mods[j];
+            ulonglong2 v =
+                reinterpret_cast<const ulonglong2 *>(g.prod)[((bc * (g.d + 1) + g.d) << (g.log_n - 1)) + c];
+            v.x = barrett64(v.x + half, P.q, P.ratio1);
+            v.y = barrett64(v.y + half, P.q, P.ratio1);
+            if (P.q > m.q)
+            {
+                v.x = barrett64(v.x, m.q, m.ratio1);
+                v.y = barrett64(v.y, m.q, m.ratio1);
+            }
+            const u64 fix = m.q - g.half_mod[(g.k - 1) * g.k + j];
+            v.x += fix;
+            v.y += fix;
+            reinterpret_cast<ulonglong2 *>(g.tmp)[i] = v;
+        }
+    }
+
+    // enc[b][comp][j] += (prod[b][comp][j] + qi_lazy - tmp[b][comp][j]) * P^-1 mod q_j   :2810-2816
+    __global__ __launch_bounds__(256) void ks_down_finish_kernel(DownArgs g)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1);
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 r = i >> (g.log_n - 1);
+            const u32 j = (u32)(r % g.d);
+            const u64 bc = r / g.d;
+            const u64 q = g.mods[j].q;
+            const MulOp pinv = g.inv_mod[(g.k - 1) * g.k + j];
+            const u64 qi_lazy = q << g.lazy_shift;
+            const ulonglong2 t = reinterpret_cast<const ulonglong2 *>(g.tmp)[i];
+            const ulonglong2 p =
+                reinterpret_cast<const ulonglong2 *>(g.prod)[((bc * (g.d + 1) + j) << (g.log_n - 1)) + c];
+            ulonglong2 *ep = reinterpret_cast<ulonglong2 *>(g.enc) + (bc >> 1) * g.enc_stride2 +
+                             (((bc & 1) * g.d + j) << (g.log_n - 1)) + c;
+            ulonglong2 e = *ep;
+            e.x = add_mod(mul_shoup(p.x + qi_lazy - t.x, pinv.op, pinv.quo, q), e.x, q);
+            e.y = add_mod(mul_shoup(p.y + qi_lazy - t.y, pinv.op, pinv.quo, q), e.y, q);
+            *ep = e;
+        }
+    }
+
+    // ---- rescale ------------------------------------------------------------------------------------------
+    struct RescaleArgs
+    {
+        const u64 *in;  // [polys][L][N]
+        const u64 *last; // [polys][N]: INTT (canonical) of the last limb (CKKS) or the last limb itself (BFV)
+        u64 *tmp;       // [polys][L-1][N]
+        u64 *out;       // [polys][L-1][N]
+        const DevMod *mods;
+        const MulOp *inv_mod;
+        const u64 *half_mod;
+        u32 L, k, log_n;
+        u64 last_stride2; // vectors between consecutive `last` polys
+        u64 total2;       // polys*(L-1)*N/2
+    };
+
+    // CKKS: tmp[p][i] = ((last + half mod q_last) mod q_i) + (q_i - half mod q_i)       rns.cpp:857-878
+    __global__ __launch_bounds__(256) void rescale_prepare_kernel(RescaleArgs g)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1);
+        const DevMod ql = g.mods[g.L - 1];
+        const u64 half = ql.q >> 1;
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 r = i >> (g.log_n - 1);
+            const u32 li = (u32)(r % (g.L - 1));
+            const u64 p = r / (g.L - 1);
+            const DevMod m = g.mods[li];
+            ulonglong2 v = reinterpret_cast<const ulonglong2 *>(g.last)[p * g.last_stride2 + c];
+            v.x = add_mod(v.x, half, ql.q);
+            v.y = add_mod(v.y, half, ql.q);
+            if (m.q < ql.q)
+            {
+                v.x = barrett64(v.x, m.q, m.ratio1);
+                v.y = barrett64(v.y, m.q, m.ratio1);
+            }
+            const u64 neg_half = m.q - g.half_mod[(g.L - 1) * g.k + li];
+            v.x += neg_half;
+            v.y += neg_half;
+            reinterpret_cast<ulonglong2 *>(g.tmp)[i] = v;
+        }
+    }
+
+    // CKKS: out[p][i] = (in[p][i] + 4 q_i - tmp[p][i]) * q_last^-1 mod q_i              rns.cpp:879-899
+    __global__ __launch_bounds__(256) void rescale_finish_kernel(RescaleArgs g)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1);
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 r = i >> (g.log_n - 1);
+            const u32 li = (u32)(r % (g.L - 1));
+            const u64 p = r / (g.L - 1);
+            const u64 q = g.mods[li].q;
+            const MulOp inv = g.inv_mod[(g.L - 1) * g.k + li];
+            const ulonglong2 t = reinterpret_cast<const ulonglong2 *>(g.tmp)[i];
+            const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(g.in)[((p * g.L + li) << (g.log_n - 1)) + c];
+            ulonglong2 o;
+            o.x = mul_shoup(x.x + (q << 2) - t.x, inv.op, inv.quo, q);
+            o.y = mul_shoup(x.y + (q << 2) - t.y, inv.op, inv.quo, q);
+            reinterpret_cast<ulonglong2 *>(g.out)[i] = o;
+        }
+    }
+
+    // BFV (coefficient domain), rns.cpp:805-827: one pass
+    __global__ __launch_bounds__(256) void rescale_coeff_kernel(RescaleArgs g)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1);
+        const DevMod ql = g.mods[g.L - 1];
+        const u64 half = ql.q >> 1;
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 r = i >> (g.log_n - 1);
+            const u32 li = (u32)(r % (g.L - 1));
+            const u64 p = r / (g.L - 1);
+            const DevMod m = g.mods[li];
+            const MulOp inv = g.inv_mod[(g.L - 1) * g.k + li];
+            const u64 half_mod = g.half_mod[(g.L - 1) * g.k + li];
+            ulonglong2 v = reinterpret_cast<const ulonglong2 *>(g.in)[((p * g.L + g.L - 1) << (g.log_n - 1)) + c];
+            const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(g.in)[((p * g.L + li) << (g.log_n - 1)) + c];
+            ulonglong2 o;
+            u64 t = sub_mod(barrett64(add_mod(v.x, half, ql.q), m.q, m.ratio1), half_mod, m.q);
+            o.x = mul_shoup(sub_mod(x.x, t, m.q), inv.op, inv.quo, m.q);
+            t = sub_mod(barrett64(add_mod(v.y, half, ql.q), m.q, m.ratio1), half_mod, m.q);
+            o.y = mul_shoup(sub_mod(x.y, t, m.q), inv.op, inv.quo, m.q);
+            reinterpret_cast<ulonglong2 *>(g.out)[i] = o;
+        }
+    }
+
+    // gather the last limb of every poly: last[p][N] = in[p][L-1][N]
+    __global__ __launch_bounds__(256) void gather_last_kernel(const u64 *in, u64 *last, u32 L, u32 log_n, u64 total2)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (log_n - 1);
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 p = i >> (log_n - 1);
+            reinterpret_cast<ulonglong2 *>(last)[i] =
+                reinterpret_cast<const ulonglong2 *>(in)[((p * L + L - 1) << (log_n - 1)) + c];
+        }
+    }
+
+    u32 grid_for(u64 items)
+    {
+        u64 blocks = (items + 255) / 256;
+        if (blocks > 256 * 16)
+            blocks = 256 * 16;
+        if (blocks == 0)
+            blocks = 1;
+        return (u32)blocks;
+    }
+} // namespace
+
+namespace cat
+{
+    cat_status launch_switch_key(cat_ctx *ctx, u64 *enc, const u64 *target, const u64 *key, uint32_t L, uint32_t batch,
+                                 size_t enc_stride, size_t target_stride, hipStream_t s)
+    {
+        const u32 d = L, k = ctx->k, rns = d + 1, log_n = ctx->log_n;
+        const size_t N = ctx->n;
+        const bool ckks = ctx->scheme == CAT_SCHEME_CKKS;
+        const size_t w_target = (size_t)batch * d * N;
+        const size_t w_ext = (size_t)batch * rns * d * N;
+        const size_t w_prod = (size_t)batch * 2 * rns * N;
+        const size_t w_tmp = (size_t)batch * 2 * d * N;
+        u64 *ws = (u64 *)workspace(ctx, (w_target + w_ext + w_prod + w_tmp) * sizeof(u64));
+        if (!ws)
+            return CAT_ERR_NOMEM;
+        u64 *t_target = ws, *ext = t_target + w_target, *prod = ext + w_ext, *tmp = prod + w_prod;
+        const LimbMap ident = ctx->identity_map();
+
+        // step 1
+        const u64 *coeff_target = target;
+        if (ckks)
+        {
+            CAT_HIP(hipMemcpy2DAsync(t_target, d * N * sizeof(u64), target, target_stride * sizeof(u64),
+                                     d * N * sizeof(u64), batch, hipMemcpyDeviceToDevice, s));
+            cat_status st = launch_ntt(ctx, false, t_target, ident, d, batch, false, s);
+            if (st != CAT_OK)
+                return st;
+            coeff_target = t_target;
+        }
+        // step 2
+        {
+            RaiseArgs g;
+            g.t_target = coeff_target;
+            g.ext = ext;
+            g.mods = ctx->d_mods;
+            g.d = d;
+            g.k = k;
+            g.log_n = log_n;
+            g.skip_diag = ckks ? 1 : 0;
+            g.src_stride2 = (ckks ? (u64)d * N : (u64)target_stride) / 2;
+            g.total2 = w_ext / 2;
+            hipLaunchKernelGGL(ks_raise_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+            CAT_HIP(hipGetLastError());
+            LimbMap map{};
+            for (u32 I = 0; I < rns; ++I)
+                map.id[I] = (unsigned char)(I == d ? k - 1 : I);
+            cat_status st = launch_ntt_ex(ctx, true, ext, map, rns * d, batch, true, (u64)rns * d * N, d, ckks, s);
+            if (st != CAT_OK)
+                return st;
+        }
+        // step 3
+        {
+            MacArgs g;
+            g.ext = ext;
+            g.target = target;
+            g.key = key;
+            g.prod = prod;
+            g.mods = ctx->d_mods;
+            g.d = d;
+            g.k = k;
+            g.log_n = log_n;
+            g.use_diag = ckks ? 1 : 0;
+            g.target_stride = target_stride;
+            g.total = (u64)batch * rns * N;
+            hipLaunchKernelGGL(ks_mac_kernel, dim3(grid_for(g.total)), dim3(256), 0, s, g);
+            CAT_HIP(hipGetLastError());
+        }
+        // step 4
+        {
+            LimbMap mp{};
+            mp.id[0] = (unsigned char)(k - 1);
+            cat_status st = launch_ntt_ex(ctx, false, prod + (size_t)d * N, mp, 1, batch * 2, true, (u64)rns * N, 1,
+                                          false, s);
+            if (st != CAT_OK)
+                return st;
+            DownArgs g;
+            g.prod = prod;
+            g.tmp = tmp;
+            g.enc = enc;
+            g.mods = ctx->d_mods;
+            g.inv_mod = ctx->d_inv_mod;
+            g.half_mod = ctx->d_half_mod;
+            g.d = d;
+            g.k = k;
+            g.log_n = log_n;
+            g.lazy_shift = ckks ? 2 : 1;
+            g.enc_stride2 = enc_stride / 2;
+            g.total2 = w_tmp / 2;
+            hipLaunchKernelGGL(ks_down_prepare_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+            CAT_HIP(hipGetLastError());
+            if (ckks)
+                st = launch_ntt(ctx, true, tmp, ident, d, batch * 2, true, s);
+            else
+                st = launch_ntt_ex(ctx, false, prod, ident, d, batch * 2, true, (u64)rns * N, 1, false, s);
+            if (st != CAT_OK)
+                return st;
+            hipLaunchKernelGGL(ks_down_finish_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+            CAT_HIP(hipGetLastError());
+        }
+        return CAT_OK;
+    }
+
+    cat_status launch_rescale(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t size, uint32_t batch,
+                              hipStream_t s)
+    {
+        const size_t N = ctx->n;
+        const u64 polys = (u64)batch * size;
+        const size_t w_last = (size_t)polys * N, w_tmp = (size_t)polys * (L - 1) * N;
+        const bool alias = (const u64 *)out == in;
+        const bool ckks = ctx->scheme != CAT_SCHEME_BFV;
+        u64 *ws = (u64 *)workspace(ctx, (w_last + 2 * w_tmp) * sizeof(u64));
+        if (!ws)
+            return CAT_ERR_NOMEM;
+        u64 *last = ws, *tmp = last + w_last, *stage = tmp + w_tmp;
+        RescaleArgs g;
+        g.in = in;
+        g.last = last;
+        g.tmp = tmp;
+        g.out = alias ? stage : out;
+        g.mods = ctx->d_mods;
+        g.inv_mod = ctx->d_inv_mod;
+        g.half_mod = ctx->d_half_mod;
+        g.L = L;
+        g.k = ctx->k;
+        g.log_n = ctx->log_n;
+        g.last_stride2 = N / 2;
+        g.total2 = w_tmp / 2;
+        if (g.total2 == 0)
+            return CAT_OK;
+        if (ckks)
+        {
+            hipLaunchKernelGGL(gather_last_kernel, dim3(grid_for(w_last / 2)), dim3(256), 0, s, in, last, L, ctx->log_n,
+                               (u64)w_last / 2);
+            CAT_HIP(hipGetLastError());
+            LimbMap ml{};
+            ml.id[0] = (unsigned char)(L - 1);
+            cat_status st = launch_ntt(ctx, false, last, ml, 1, (uint32_t)polys, false, s);
+            if (st != CAT_OK)
+                return st;
+            hipLaunchKernelGGL(rescale_prepare_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+            CAT_HIP(hipGetLastError());
+            st = launch_ntt(ctx, true, tmp, ctx->identity_map(), L - 1, (uint32_t)polys, true, s);
+            if (st != CAT_OK)
+                return st;
+            hipLaunchKernelGGL(rescale_finish_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+            CAT_HIP(hipGetLastError());
+        }
+        else
+        {
+            hipLaunchKernelGGL(rescale_coeff_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+            CAT_HIP(hipGetLastError());
+        }
+        if (alias)
+            CAT_HIP(hipMemcpyAsync(out, stage, w_tmp * sizeof(u64), hipMemcpyDeviceToDevice, s));
+        return CAT_OK;
+    }
+} // namespace cat

@@ -1,0 +1,189 @@
+/*
+ * cat_amd.h -- C ABI of the MI355X-native RNS polynomial arithmetic library (libcat_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of Rayman96/CAT (a CUDA fork of SEAL 4.0): every
+ * entry point below names the reference interface it replaces (file:line, paths relative to
+ * /root/reference/native/src/seal/).  The reference has no FFI layer of its own (the CUDA code is
+ * compiled into the seal:: classes); the C++ facade in cat_amd/host/seal_hip.hpp binds
+ * these symbols behind the reference's class and function names.
+ *
+ * Conventions
+ *  - All pointers named d_* are DEVICE pointers (hipMalloc'ed or torch-owned), 8-byte aligned.
+ *  - Polynomial layout is the reference's: poly[limb][coeff], limbs contiguous, N words each
+ *    (RNSIter, util/iterator.h:951); a ciphertext is size x L x N words (ciphertext.cuh:423-434);
+ *    a batch is `batch` such objects back to back.
+ *  - Limb i of a level-L object is reduced modulo primes[i] of the context (context.cu:607-637).
+ *  - Every call returns a cat_status, takes an explicit stream (hipStream_t as void*, NULL = default
+ *    stream), is asynchronous with respect to the host, never throws and never exits.
+ *  - Error codes mirror the reference's exceptions (evaluator.cpp:2534-2573): CAT_ERR_INVALID_ARG =
+ *    std::invalid_argument, CAT_ERR_LOGIC = std::logic_error, CAT_ERR_OUT_OF_RANGE =
+ *    std::out_of_range.  cat_last_error() returns the message of the calling thread's last failure.
+ *  - Temporaries come from a context-owned device workspace that grows on demand (hipMalloc happens
+ *    only when a call needs more than any earlier call; cat_ctx_reserve() pre-sizes it).
+ *  - One context per device and per host thread of control; calls on one context must not overlap.
+ */
+#ifndef CAT_AMD_H
+#define CAT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cat_ctx cat_ctx;
+typedef void *cat_stream; /* hipStream_t */
+
+typedef enum {
+    CAT_OK = 0,
+    CAT_ERR_INVALID_ARG = 1,
+    CAT_ERR_LOGIC = 2,
+    CAT_ERR_OUT_OF_RANGE = 3,
+    CAT_ERR_HIP = 4,
+    CAT_ERR_NOMEM = 5
+} cat_status;
+
+enum { CAT_SCHEME_NONE = 0, CAT_SCHEME_BFV = 1, CAT_SCHEME_CKKS = 2 };
+
+#define CAT_MAX_MODULI 64 /* coefficient primes + BFV auxiliary primes per context */
+#define CAT_MAX_LOG_N 16
+#define CAT_MIN_LOG_N 1
+
+/* ---- library / context -------------------------------------------------------------------------- */
+
+const char *cat_version(void);
+const char *cat_last_error(void);
+
+/* Replaces SEALContext construction for this path (context.cu:292-356, 607-765): validates the
+ * primes (prime, = 1 mod 2N, <= 61 bits), builds per-prime NTTTables (util/ntt.cpp:240-299), Barrett
+ * ratios (modulus.cpp:87-98), q_a^-1 mod q_b tables (util/rns.cpp:767-776) and, for BFV, the BEHZ
+ * bases of every level (util/rns.cpp:578-787), and uploads them to `device`.
+ * primes[0..n_primes) is the key-level chain; when n_primes > 1 the last prime is the special prime
+ * of key switching.  plain_modulus is used by BFV only. */
+cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_primes, int scheme,
+                          uint64_t plain_modulus, int device, cat_ctx **out);
+cat_status cat_ctx_destroy(cat_ctx *ctx);
+cat_status cat_ctx_reserve(cat_ctx *ctx, size_t workspace_bytes);
+size_t cat_ctx_workspace_bytes(const cat_ctx *ctx);
+uint32_t cat_ctx_log_n(const cat_ctx *ctx);
+uint32_t cat_ctx_n_primes(const cat_ctx *ctx);
+/* NTTTables::get_root() (util/ntt.h:101): the minimal primitive 2N-th root used for prime i */
+uint64_t cat_ctx_root(const cat_ctx *ctx, uint32_t prime_index);
+/* Number of moduli known to the context (coefficient primes first, then BFV auxiliary primes:
+ * m_sk, gamma, B_0.., util/rns.cpp:625-635) and their values. */
+uint32_t cat_ctx_n_moduli(const cat_ctx *ctx);
+uint64_t cat_ctx_modulus(const cat_ctx *ctx, uint32_t modulus_index);
+
+/* Device memory helpers (Ciphertext::to_gpu/to_cpu, ciphertext.cuh:361-381).  Optional: any device
+ * pointer works with the calls below. */
+cat_status cat_malloc(cat_ctx *ctx, size_t bytes, void **d_ptr);
+cat_status cat_free(cat_ctx *ctx, void *d_ptr);
+cat_status cat_upload(cat_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, cat_stream s);
+cat_status cat_download(cat_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, cat_stream s);
+cat_status cat_stream_sync(cat_ctx *ctx, cat_stream s);
+
+/* ---- a1/a2/a13: negacyclic NTT -------------------------------------------------------------------
+ * util::ntt_negacyclic_harvey[_lazy] (util/ntt.cpp:393-436, ntt.h:201-270) and
+ * util::inverse_ntt_negacyclic_harvey[_lazy] (util/ntt.cpp:438-474), batched: d_data holds n_polys
+ * objects of n_limbs limbs; limb j is transformed with the tables of modulus limb_ids[j]
+ * (limb_ids == NULL means 0..n_limbs-1).  In place.  Forward: input < 4q, output bit-reversed order,
+ * < 4q when lazy else < q.  Inverse: input < 2q bit-reversed order, output < 2q when lazy else < q.
+ * The lazy outputs are the reference's exact representatives (same butterfly network). */
+cat_status cat_ntt_forward(cat_ctx *ctx, uint64_t *d_data, const uint32_t *limb_ids, uint32_t n_limbs,
+                           uint32_t n_polys, int lazy, cat_stream s);
+cat_status cat_ntt_inverse(cat_ctx *ctx, uint64_t *d_data, const uint32_t *limb_ids, uint32_t n_limbs,
+                           uint32_t n_polys, int lazy, cat_stream s);
+
+/* ---- a4/a5/a6: coefficient-wise ops (util/polyarithsmallmod.cpp:18-285) ---------------------------
+ * Operands are n_polys x n_limbs x N; limb j uses modulus limb_ids[j] (NULL = 0..n_limbs-1).
+ * Outputs may alias inputs. */
+cat_status cat_add(cat_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out,
+                   const uint32_t *limb_ids, uint32_t n_limbs, uint32_t n_polys, cat_stream s); /* :43-86 */
+cat_status cat_sub(cat_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out,
+                   const uint32_t *limb_ids, uint32_t n_limbs, uint32_t n_polys, cat_stream s); /* :88-131 */
+cat_status cat_negate(cat_ctx *ctx, const uint64_t *d_a, uint64_t *d_out, const uint32_t *limb_ids,
+                      uint32_t n_limbs, uint32_t n_polys, cat_stream s); /* .cuh:84-117 */
+cat_status cat_dyadic(cat_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out,
+                      const uint32_t *limb_ids, uint32_t n_limbs, uint32_t n_polys, cat_stream s); /* :227-285 */
+/* scalars[j] is the scalar of limb j (any 64-bit value; reduced mod q_j first, .cuh:477-486) */
+cat_status cat_mul_scalar(cat_ctx *ctx, const uint64_t *d_a, const uint64_t *scalars, uint64_t *d_out,
+                          const uint32_t *limb_ids, uint32_t n_limbs, uint32_t n_polys, cat_stream s); /* :193-225 */
+/* scalars[j] must be < q_j (the reference's precondition, :150-153) */
+cat_status cat_add_scalar(cat_ctx *ctx, const uint64_t *d_a, const uint64_t *scalars, uint64_t *d_out,
+                          const uint32_t *limb_ids, uint32_t n_limbs, uint32_t n_polys, cat_stream s); /* :133-161 */
+cat_status cat_sub_scalar(cat_ctx *ctx, const uint64_t *d_a, const uint64_t *scalars, uint64_t *d_out,
+                          const uint32_t *limb_ids, uint32_t n_limbs, uint32_t n_polys, cat_stream s); /* :163-191 */
+cat_status cat_modulo(cat_ctx *ctx, const uint64_t *d_a, uint64_t *d_out, const uint32_t *limb_ids,
+                      uint32_t n_limbs, uint32_t n_polys, cat_stream s); /* :18-41 */
+
+/* ---- a7: Evaluator::ckks_multiply, size 2 x 2 -> 3 (evaluator.cpp:569-708) -------------------------
+ * d_x: batch x 2 x L x N, d_y: batch x 2 x L x N, d_out: batch x 3 x L x N (NTT form).  d_out must
+ * not alias the inputs. */
+cat_status cat_ckks_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, uint64_t *d_out, uint32_t L,
+                             uint32_t batch, cat_stream s);
+
+/* ---- a8: Evaluator::switch_key_inplace (evaluator.cpp:2523-2820), CKKS and BFV branches ------------
+ * d_encrypted: batch x 2 x L x N, updated in place (encrypted[comp][j] += mod-down result).
+ * d_target:    batch x L x N (NTT form for CKKS, coefficient form for BFV); must not alias d_encrypted.
+ * d_key:       one KSwitchKeys::data()[index] entry = [n_primes-1][2][n_primes][N] words, NTT form
+ *              (kswitchkeys.h:90-101), shared by the whole batch.
+ * Errors: L == 0 or L >= n_primes -> CAT_ERR_INVALID_ARG; scheme NONE -> CAT_ERR_LOGIC
+ * ("keyswitching is not supported by the context", :2543-2546). */
+cat_status cat_switch_key(cat_ctx *ctx, uint64_t *d_encrypted, const uint64_t *d_target, const uint64_t *d_key,
+                          uint32_t L, uint32_t batch, cat_stream s);
+/* Evaluator::relinearize_internal for size 3 -> 2 (evaluator.cpp:1144-1199): d_ct3 is
+ * batch x 3 x L x N; on return the first two polys of each ciphertext hold the result (the caller
+ * "resizes" by ignoring the third).  d_key = RelinKeys key of index get_index(2) = 0 (relinkeys.h:58-64). */
+cat_status cat_relinearize(cat_ctx *ctx, uint64_t *d_ct3, const uint64_t *d_key, uint32_t L, uint32_t batch,
+                           cat_stream s);
+
+/* ---- a9/a10: mod switching ------------------------------------------------------------------------
+ * Evaluator::mod_switch_scale_to_next (evaluator.cpp:1201-1280) = rescale_to_next (:1481-1519):
+ * CKKS: RNSTool::divide_and_round_q_last_ntt_inplace (util/rns.cpp:830-901); BFV:
+ * divide_and_round_q_last_inplace (:789-828).  d_in: batch x size x L x N -> d_out: batch x size x
+ * (L-1) x N.  d_out may equal d_in (the compaction is ordered).  The `scale_ /= q_last` bookkeeping
+ * (:1271) stays with the caller. */
+cat_status cat_rescale(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t size,
+                       uint32_t batch, cat_stream s);
+/* Evaluator::mod_switch_drop_to_next (evaluator.cpp:1282-1345): drop the last limb of every poly. */
+cat_status cat_mod_drop(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t size,
+                        uint32_t batch, cat_stream s);
+
+/* ---- a11: Galois ------------------------------------------------------------------------------------
+ * GaloisTool::get_elt_from_step (util/galois.cpp:53-95); returns 0 when |step| >= N/2 (the reference
+ * throws invalid_argument("step count too large")). */
+uint32_t cat_galois_elt_from_step(uint32_t log_n, int step);
+/* GaloisTool::apply_galois_ntt (util/galois.cpp:192-218) / apply_galois (:148-190) on n_polys x n_limbs
+ * x N; d_out must not alias d_in (:160-163 -> CAT_ERR_INVALID_ARG). */
+cat_status cat_apply_galois_ntt(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t galois_elt,
+                                uint32_t n_limbs, uint32_t n_polys, cat_stream s);
+cat_status cat_apply_galois(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t galois_elt,
+                            const uint32_t *limb_ids, uint32_t n_limbs, uint32_t n_polys, cat_stream s);
+/* Evaluator::apply_galois_inplace (evaluator.cpp:2362-2464) on batch x 2 x L x N ciphertexts with one
+ * GaloisKeys entry (index GaloisKeys::get_index(elt), galoiskeys.h:48-50); rotate_vector is this with
+ * elt = cat_galois_elt_from_step(step) (evaluator.cpp:2466-2521). */
+cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *d_ct, uint32_t galois_elt, const uint64_t *d_key,
+                                    uint32_t L, uint32_t batch, cat_stream s);
+
+/* ---- a12: Evaluator::bfv_multiply, size 2 x 2 -> 3 (evaluator.cpp:395-567) with the BEHZ tool
+ * (util/rns.cpp:418-463, 903-1131).  d_x, d_y: batch x 2 x L x N coefficient form; d_out: batch x 3 x L x N. */
+cat_status cat_bfv_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, uint64_t *d_out, uint32_t L,
+                            uint32_t batch, cat_stream s);
+/* BEHZ pieces, exposed for parity tests against tests/util/rns.cpp:460-853.  All operate on one
+ * polynomial of the level with L limbs: q-limbs first, then Bsk (B primes, m_sk), then m_tilde. */
+uint32_t cat_bfv_base_Bsk_size(const cat_ctx *ctx, uint32_t L);
+cat_status cat_bfv_base_Bsk(const cat_ctx *ctx, uint32_t L, uint64_t *out_moduli);
+cat_status cat_fastbconv_m_tilde(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys,
+                                 cat_stream s); /* rns.cpp:1092-1131: q -> Bsk U {m_tilde} */
+cat_status cat_sm_mrq(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys,
+                      cat_stream s); /* rns.cpp:981-1041: Bsk U {m_tilde} -> Bsk */
+cat_status cat_fast_floor(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys,
+                          cat_stream s); /* rns.cpp:1043-1090: q U Bsk -> Bsk */
+cat_status cat_fastbconv_sk(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys,
+                            cat_stream s); /* rns.cpp:903-979: Bsk -> q */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,323 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs, bit-exact (integer work: no tolerance), plus the reference's own known answers."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KA = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+@pytest.fixture(scope="module")
+def cat():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import cat_amd
+
+    return cat_amd
+
+
+def dev(a):
+    from cat_amd.api import to_device
+
+    return to_device(np.ascontiguousarray(a))
+
+
+def host(t):
+    from cat_amd.api import to_host
+
+    return to_host(t)
+
+
+def rand_limbs(rng, primes, shape_prefix, n, mult=1):
+    """uniform in [0, mult*q_j) per limb; shape prefix + [len(primes), n]"""
+    out = np.empty(tuple(shape_prefix) + (len(primes), n), dtype=np.uint64)
+    for j, q in enumerate(primes):
+        out[..., j, :] = rng.integers(0, mult * q, size=tuple(shape_prefix) + (n,), dtype=np.uint64)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ NTT
+
+
+@pytest.mark.parametrize("log_n", list(range(1, 17)))
+def test_ntt_matches_oracle_all_sizes(cat, oracle, log_n):
+    n = 1 << log_n
+    primes = oracle.get_primes(2 * n, 60, 2) + oracle.get_primes(2 * n, 61, 1) + oracle.get_primes(2 * n, 49, 1)
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_NONE)
+    for i in range(len(primes)):
+        assert ctx.root(i) == octx_root(oracle, log_n, primes[i])
+    rng = np.random.default_rng(100 + log_n)
+    polys = 3 if log_n <= 13 else 2
+    ids = list(range(len(primes)))
+    x = rand_limbs(rng, primes, (polys,), n)
+    x[0, :, : min(n, 4)] = 0
+    x[0, :, -1] = np.array(primes, dtype=np.uint64) - 1
+    for lazy in (False, True):
+        got = host(ctx.ntt_forward(dev(x), lazy=lazy))
+        exp = octx.ntt_forward(x, ids, lazy=lazy)
+        assert (got == exp).all(), f"forward lazy={lazy}"
+        got_i = host(ctx.ntt_inverse(dev(exp if not lazy else exp % np.array(primes, dtype=np.uint64)[None, :, None]),
+                                     lazy=lazy))
+        exp_i = octx.ntt_inverse(exp if not lazy else exp % np.array(primes, dtype=np.uint64)[None, :, None], ids,
+                                 lazy=lazy)
+        assert (got_i == exp_i).all(), f"inverse lazy={lazy}"
+        if not lazy:
+            assert (got_i == x).all()
+    # documented input ranges: forward accepts [0, 4q), inverse accepts [0, 2q)
+    x4 = rand_limbs(rng, primes, (1,), n, mult=4)
+    assert (host(ctx.ntt_forward(dev(x4), lazy=True)) == octx.ntt_forward(x4, ids, lazy=True)).all()
+    x2 = rand_limbs(rng, primes, (1,), n, mult=2)
+    assert (host(ctx.ntt_inverse(dev(x2), lazy=True)) == octx.ntt_inverse(x2, ids, lazy=True)).all()
+    # limb_ids permutation / subset
+    sub = [3, 1]
+    xs = rand_limbs(rng, [primes[i] for i in sub], (2,), n)
+    assert (host(ctx.ntt_forward(dev(xs), limb_ids=sub)) == octx.ntt_forward(xs, sub)).all()
+    ctx.close()
+
+
+def octx_root(oracle, log_n, q):
+    import ctypes as C
+
+    m = oracle.modulus(q)
+    r = C.c_uint64(0)
+    assert oracle.lib().so_try_minimal_primitive_root(2 << log_n, C.byref(m), C.byref(r)) == 1
+    return r.value
+
+
+def test_ntt_reference_known_answers(cat):
+    # tests/util/ntt.cpp:77-101 through the HIP path
+    g = KA["ntt_n2"]
+    ctx = cat.Context(1, [g["modulus"]], cat.SCHEME_NONE)
+    for x, y in g["cases"]:
+        got = host(ctx.ntt_forward(dev(np.array([[x]], dtype=np.uint64))))
+        assert got.reshape(-1).tolist() == y
+    ctx.close()
+
+
+def test_ntt_empty_batch_is_a_noop(cat):
+    import torch
+
+    ctx = cat.Context(12, [KA["get_primes_cfg2"]["first"]], cat.SCHEME_NONE)
+    x = torch.empty((0, 1, 4096), dtype=torch.int64, device="cuda")
+    ctx.ntt_forward(x)
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------- coefficient-wise
+
+
+@pytest.mark.parametrize("log_n", [1, 3, 12])
+def test_coefficientwise_ops_match_oracle(cat, oracle, log_n):
+    import ctypes as C
+
+    n = 1 << log_n
+    primes = oracle.get_primes(2 * n, 60, 2) + oracle.get_primes(2 * n, 61, 1) + oracle.get_primes(2 * n, 30, 1)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_NONE)
+    rng = np.random.default_rng(7)
+    a = rand_limbs(rng, primes, (3,), n)
+    b = rand_limbs(rng, primes, (3,), n)
+    qs = np.array(primes, dtype=np.uint64)
+    a[0, :, 0] = 0
+    b[0, :, 0] = 0
+    a[0, :, 1] = qs - 1
+    b[0, :, 1] = qs - 1
+    lib = oracle.lib()
+    mods = [oracle.modulus(q) for q in primes]
+
+    def per_limb(fn, *arrs, scalar=None):
+        out = np.zeros_like(arrs[0])
+        for p in range(out.shape[0]):
+            for j in range(len(primes)):
+                args = [oracle.ptr(np.ascontiguousarray(x[p, j])) for x in arrs]
+                o = np.zeros(n, dtype=np.uint64)
+                if scalar is None:
+                    fn(*args, n, C.byref(mods[j]), oracle.ptr(o))
+                else:
+                    fn(*args, n, int(scalar[j]), C.byref(mods[j]), oracle.ptr(o))
+                out[p, j] = o
+        return out
+
+    da, db = dev(a), dev(b)
+    assert (host(ctx.add(da, db)) == per_limb(lib.so_add_poly_coeffmod, a, b)).all()
+    assert (host(ctx.sub(da, db)) == per_limb(lib.so_sub_poly_coeffmod, a, b)).all()
+    assert (host(ctx.negate(da)) == per_limb(lib.so_negate_poly_coeffmod, a)).all()
+    assert (host(ctx.dyadic(da, db)) == per_limb(lib.so_dyadic_product_coeffmod, a, b)).all()
+    # lazy inputs (< 4q) to dyadic, as bfv_multiply feeds it (evaluator.cpp:497-541)
+    a4 = rand_limbs(rng, primes, (3,), n, mult=4)
+    assert (host(ctx.dyadic(dev(a4), db)) == per_limb(lib.so_dyadic_product_coeffmod, a4, b)).all()
+    raw = rng.integers(0, 1 << 63, size=a.shape, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    assert (host(ctx.modulo(dev(raw))) == per_limb(lib.so_modulo_poly_coeffs, raw)).all()
+    sc = [int(rng.integers(0, 1 << 63)) * 2 + 1 for _ in primes]
+    assert (host(ctx.mul_scalar(da, sc)) == per_limb(lib.so_multiply_poly_scalar_coeffmod, a, scalar=sc)).all()
+    # Shoup scalar multiply accepts any 64-bit x (uintarithsmallmod.cu:258-266)
+    assert (host(ctx.mul_scalar(dev(raw), sc)) == per_limb(lib.so_multiply_poly_scalar_coeffmod, raw, scalar=sc)).all()
+    sc2 = [int(rng.integers(0, q)) for q in primes]
+    assert (host(ctx.add_scalar(da, sc2)) == per_limb(lib.so_add_poly_scalar_coeffmod, a, scalar=sc2)).all()
+    assert (host(ctx.sub_scalar(da, sc2)) == per_limb(lib.so_sub_poly_scalar_coeffmod, a, scalar=sc2)).all()
+    with pytest.raises(ValueError):
+        ctx.add_scalar(da, [q for q in primes])  # scalar >= modulus (polyarithsmallmod.cpp:150-153)
+    # aliasing: result == operand1 (evaluator.cpp:652-653)
+    exp = per_limb(lib.so_dyadic_product_coeffmod, a, b)
+    ctx.dyadic(da, db, out=da)
+    assert (host(da) == exp).all()
+    ctx.close()
+
+
+def test_galois_permutations(cat, oracle):
+    import ctypes as C
+
+    # reference vectors (tests/util/galois.cpp:79-113): N=8, q=17, elt=3
+    ctx = cat.Context(3, [17], cat.SCHEME_NONE)
+    x = dev(np.array([[KA["apply_galois"]["in"]]], dtype=np.uint64))
+    assert host(ctx.apply_galois(x, 3)).reshape(-1).tolist() == KA["apply_galois"]["out"]
+    assert host(ctx.apply_galois_ntt(x, 3)).reshape(-1).tolist() == KA["apply_galois_ntt"]["out"]
+    with pytest.raises(ValueError):
+        ctx.apply_galois_ntt(x, 3, out=x)  # galois.cpp:160-163
+    with pytest.raises(ValueError):
+        ctx.apply_galois_ntt(x, 4)
+    ctx.close()
+    log_n = 13
+    n = 1 << log_n
+    primes = oracle.get_primes(2 * n, 55, 3)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_NONE)
+    rng = np.random.default_rng(9)
+    a = rand_limbs(rng, primes, (2,), n)
+    for elt in (3, 2 * n - 1, cat.galois_elt_from_step(log_n, -5)):
+        e1, e2 = np.zeros_like(a), np.zeros_like(a)
+        for p in range(2):
+            for j, q in enumerate(primes):
+                m = oracle.modulus(q)
+                src = np.ascontiguousarray(a[p, j])
+                o = np.zeros(n, dtype=np.uint64)
+                oracle.lib().so_apply_galois_ntt(oracle.ptr(src), log_n, elt, oracle.ptr(o))
+                e1[p, j] = o
+                oracle.lib().so_apply_galois(oracle.ptr(src), log_n, elt, C.byref(m), oracle.ptr(o))
+                e2[p, j] = o
+        assert (host(ctx.apply_galois_ntt(dev(a), elt)) == e1).all()
+        assert (host(ctx.apply_galois(dev(a), elt)) == e2).all()
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------ evaluator level
+
+CKKS_CASES = [
+    # (log_n, bit sizes of the key-level chain)
+    (12, [50, 40, 40, 50]),
+    (13, [60, 40, 40, 60]),  # BASELINE config 1 parameters (4_ckks_basics upstream)
+    (12, [60, 60, 60, 60, 60]),  # all-60-bit chain: special prime is the largest
+]
+
+
+@pytest.mark.parametrize("log_n,bits", CKKS_CASES)
+def test_ckks_multiply_relinearize_rescale_chain(cat, oracle, log_n, bits):
+    n = 1 << log_n
+    primes = oracle.coeff_modulus_create(n, bits)
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_CKKS)
+    k = len(primes)
+    sk = octx.secret_key(3)
+    rk = octx.relin_key(sk, 4)
+    drk = dev(rk)
+    batch = 3
+    for L in range(k - 1, 1, -1):
+        x = np.stack([octx.uniform(L, 2, 1000 + 10 * L + b) for b in range(batch)])
+        y = np.stack([octx.uniform(L, 2, 2000 + 10 * L + b) for b in range(batch)])
+        prod = ctx.ckks_multiply(dev(x), dev(y))
+        exp3 = np.stack([octx.ckks_multiply(x[b], y[b]) for b in range(batch)])
+        assert (host(prod) == exp3).all(), f"ckks_multiply L={L}"
+        relin = ctx.relinearize(prod, drk)
+        exp2 = np.stack([octx.relinearize(exp3[b], rk) for b in range(batch)])
+        assert (host(relin.contiguous()) == exp2).all(), f"relinearize L={L}"
+        res = ctx.rescale(relin.contiguous())
+        expr = np.stack([octx.rescale(exp2[b]) for b in range(batch)])
+        assert (host(res) == expr).all(), f"rescale L={L}"
+        # in-place rescale and mod_drop
+        buf = dev(exp2)
+        ctx.rescale(buf, out=buf.view(-1)[: batch * 2 * (L - 1) * n].view(batch, 2, L - 1, n))
+        assert (host(buf).reshape(-1)[: expr.size] == expr.reshape(-1)).all()
+        drop = ctx.mod_drop(dev(exp2))
+        assert (host(drop) == np.stack([octx.mod_drop(exp2[b]) for b in range(batch)])).all()
+        buf = dev(exp2)
+        ctx.mod_drop(buf, out=buf.view(-1)[: batch * 2 * (L - 1) * n].view(batch, 2, L - 1, n))
+        assert (host(buf).reshape(-1)[: expr.size] == host(drop).reshape(-1)).all()
+    ctx.close()
+
+
+def test_switch_key_direct_and_rotate(cat, oracle):
+    log_n = 12
+    n = 1 << log_n
+    primes = oracle.coeff_modulus_create(n, [55, 45, 45, 45, 55])
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_CKKS)
+    sk = octx.secret_key(5)
+    batch = 2
+    for L in (4, 2, 1):
+        enc = np.stack([octx.uniform(L, 2, 300 + b + L) for b in range(batch)])
+        tgt = np.stack([octx.uniform(L, 1, 400 + b + L)[0] for b in range(batch)])
+        key = octx.relin_key(sk, 6)
+        got = host(ctx.switch_key(dev(enc), dev(tgt), dev(key)))
+        exp = np.stack([octx.switch_key_inplace(enc[b], tgt[b], key) for b in range(batch)])
+        assert (got == exp).all(), f"switch_key L={L}"
+        for step in (1, -3):
+            elt = cat.galois_elt_from_step(log_n, step)
+            gk = octx.galois_key(sk, elt, 7)
+            got = host(ctx.rotate_vector(dev(enc), step, dev(gk)))
+            exp = np.stack([octx.apply_galois_inplace(enc[b], elt, gk) for b in range(batch)])
+            assert (got == exp).all(), f"rotate L={L} step={step}"
+    # error behaviour mirrors evaluator.cpp:2534-2573
+    enc = dev(np.stack([octx.uniform(5, 2, 1)]))
+    with pytest.raises(ValueError):
+        ctx.switch_key(enc, dev(octx.uniform(5, 1, 2)), dev(octx.relin_key(sk, 6)))  # L == k: no such data level
+    none = cat.Context(log_n, primes, cat.SCHEME_NONE)
+    with pytest.raises(RuntimeError):
+        none.switch_key(dev(octx.uniform(2, 2, 1)[None]), dev(octx.uniform(2, 1, 2)), dev(octx.relin_key(sk, 6)))
+    none.close()
+    ctx.close()
+
+
+def test_bfv_switch_key_rescale_and_galois_branches(cat, oracle):
+    log_n = 12
+    n = 1 << log_n
+    primes = oracle.coeff_modulus_create(n, [40, 40, 40, 41])
+    t = 65537
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_BFV, t)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_BFV, t)
+    sk = octx.secret_key(8)
+    rk = octx.relin_key(sk, 9)
+    batch = 2
+    for L in (3, 2):
+        ct3 = np.stack([octx.uniform(L, 3, 500 + b + L) for b in range(batch)])
+        got = host(ctx.relinearize(dev(ct3), dev(rk)).contiguous())
+        exp = np.stack([octx.relinearize(ct3[b], rk) for b in range(batch)])
+        assert (got == exp).all(), f"bfv relinearize L={L}"
+        res = host(ctx.rescale(dev(exp)))
+        assert (res == np.stack([octx.rescale(exp[b]) for b in range(batch)])).all(), f"bfv mod switch L={L}"
+        elt = 3
+        gk = octx.galois_key(sk, elt, 10)
+        got = host(ctx.apply_galois_inplace(dev(exp), elt, dev(gk)))
+        assert (got == np.stack([octx.apply_galois_inplace(exp[b], elt, gk) for b in range(batch)])).all()
+    ctx.close()
+
+
+def test_rescale_reference_known_answers(cat, oracle):
+    # tests/util/rns.cpp:1013-1072 through the HIP path: q = {53, 13}, N = 2
+    g = KA["divide_and_round_q_last_ntt"]
+    q = g["q"]
+    ctx = cat.Context(1, q, cat.SCHEME_CKKS)
+    tabs = [oracle.NTTTables(1, p) for p in q]
+    for xin, exp, tol in g["cases"]:
+        x = np.array(xin, dtype=np.uint64)
+        x[:2] = tabs[0].forward(x[:2])
+        x[2:] = tabs[1].forward(x[2:])
+        out = host(ctx.rescale(dev(x.reshape(1, 1, 2, 2))))
+        res = tabs[0].inverse(out.reshape(-1))
+        for j in range(2):
+            assert (q[0] + exp[j] - int(res[j])) % q[0] <= tol
+    ctx.close()
