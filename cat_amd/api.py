@@ -184,6 +184,13 @@ class Context:
         _check(self.lib.cat_rescale(self.h, self._p(ct), self._p(out), L, size, b, self._stream()))
         return out
 
+    def rescale_strided(self, ct, size, out):
+        """ct: [batch, S, L, N] of which the first `size` polys are the ciphertext (stride S*L*N)."""
+        b, S, L, _ = ct.shape
+        _check(self.lib.cat_rescale_strided(self.h, self._p(ct), S * L * self.n, self._p(out),
+                                            out.shape[1] * (L - 1) * self.n, L, size, b, self._stream()))
+        return out
+
     def mod_drop(self, ct, out=None):
         b, size, L, _ = ct.shape
         out = torch.empty((b, size, L - 1, self.n), dtype=torch.int64, device=ct.device) if out is None else out

@@ -530,7 +530,24 @@ cat_status cat_rescale(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t
         return st;
     if (size * batch && (!in || !out))
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
-    return launch_rescale(ctx, (const u64 *)in, (u64 *)out, L, size, batch, (hipStream_t)s);
+    return launch_rescale(ctx, (const u64 *)in, (u64 *)out, L, size, batch, (size_t)size * L * ctx->n,
+                          (size_t)size * (L - 1) * ctx->n, (hipStream_t)s);
+}
+
+cat_status cat_rescale_strided(cat_ctx *ctx, const uint64_t *in, size_t in_stride, uint64_t *out, size_t out_stride,
+                               uint32_t L, uint32_t size, uint32_t batch, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if ((st = level_check(ctx, L, true)) != CAT_OK)
+        return st;
+    if (size * batch && (!in || !out))
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (in_stride < (size_t)size * L * ctx->n || out_stride < (size_t)size * (L - 1) * ctx->n || (in_stride & 1) ||
+        (out_stride & 1))
+        return fail(CAT_ERR_INVALID_ARG, "stride");
+    return launch_rescale(ctx, (const u64 *)in, (u64 *)out, L, size, batch, in_stride, out_stride, (hipStream_t)s);
 }
 
 cat_status cat_mod_drop(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t L, uint32_t size, uint32_t batch,

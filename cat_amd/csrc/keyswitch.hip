@@ -180,10 +180,22 @@ namespace
         const DevMod *mods;
         const MulOp *inv_mod;
         const u64 *half_mod;
-        u32 L, k, log_n;
+        u32 L, k, log_n, size;
         u64 last_stride2; // vectors between consecutive `last` polys
+        u64 in_stride2;   // vectors between consecutive input ciphertexts
+        u64 out_stride2;  // vectors between consecutive output ciphertexts
         u64 total2;       // polys*(L-1)*N/2
     };
+
+    // vector offset of limb li of poly p (= b*size + s) in the input / output batch
+    __device__ __forceinline__ u64 rs_in(const RescaleArgs &g, u64 p, u32 li)
+    {
+        return (p / g.size) * g.in_stride2 + (((p % g.size) * g.L + li) << (g.log_n - 1));
+    }
+    __device__ __forceinline__ u64 rs_out(const RescaleArgs &g, u64 p, u32 li)
+    {
+        return (p / g.size) * g.out_stride2 + (((p % g.size) * (g.L - 1) + li) << (g.log_n - 1));
+    }
 
     // CKKS: tmp[p][i] = ((last + half mod q_last) mod q_i) + (q_i - half mod q_i)       rns.cpp:857-878
     __global__ __launch_bounds__(256) void rescale_prepare_kernel(RescaleArgs g)
@@ -228,11 +240,11 @@ namespace
             const u64 q = g.mods[li].q;
             const MulOp inv = g.inv_mod[(g.L - 1) * g.k + li];
             const ulonglong2 t = reinterpret_cast<const ulonglong2 *>(g.tmp)[i];
-            const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(g.in)[((p * g.L + li) << (g.log_n - 1)) + c];
+            const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(g.in)[rs_in(g, p, li) + c];
             ulonglong2 o;
             o.x = mul_shoup(x.x + (q << 2) - t.x, inv.op, inv.quo, q);
             o.y = mul_shoup(x.y + (q << 2) - t.y, inv.op, inv.quo, q);
-            reinterpret_cast<ulonglong2 *>(g.out)[i] = o;
+            reinterpret_cast<ulonglong2 *>(g.out)[rs_out(g, p, li) + c] = o;
         }
     }
 
@@ -252,28 +264,27 @@ namespace
             const DevMod m = g.mods[li];
             const MulOp inv = g.inv_mod[(g.L - 1) * g.k + li];
             const u64 half_mod = g.half_mod[(g.L - 1) * g.k + li];
-            ulonglong2 v = reinterpret_cast<const ulonglong2 *>(g.in)[((p * g.L + g.L - 1) << (g.log_n - 1)) + c];
-            const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(g.in)[((p * g.L + li) << (g.log_n - 1)) + c];
+            ulonglong2 v = reinterpret_cast<const ulonglong2 *>(g.in)[rs_in(g, p, g.L - 1) + c];
+            const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(g.in)[rs_in(g, p, li) + c];
             ulonglong2 o;
             u64 t = sub_mod(barrett64(add_mod(v.x, half, ql.q), m.q, m.ratio1), half_mod, m.q);
             o.x = mul_shoup(sub_mod(x.x, t, m.q), inv.op, inv.quo, m.q);
             t = sub_mod(barrett64(add_mod(v.y, half, ql.q), m.q, m.ratio1), half_mod, m.q);
             o.y = mul_shoup(sub_mod(x.y, t, m.q), inv.op, inv.quo, m.q);
-            reinterpret_cast<ulonglong2 *>(g.out)[i] = o;
+            reinterpret_cast<ulonglong2 *>(g.out)[rs_out(g, p, li) + c] = o;
         }
     }
 
     // gather the last limb of every poly: last[p][N] = in[p][L-1][N]
-    __global__ __launch_bounds__(256) void gather_last_kernel(const u64 *in, u64 *last, u32 L, u32 log_n, u64 total2)
+    __global__ __launch_bounds__(256) void gather_last_kernel(RescaleArgs g, u64 *last, u64 total2)
     {
         const u64 stride = (u64)gridDim.x * blockDim.x;
-        const u32 n2 = 1u << (log_n - 1);
+        const u32 n2 = 1u << (g.log_n - 1);
         for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += stride)
         {
             const u32 c = (u32)(i & (n2 - 1));
-            const u64 p = i >> (log_n - 1);
-            reinterpret_cast<ulonglong2 *>(last)[i] =
-                reinterpret_cast<const ulonglong2 *>(in)[((p * L + L - 1) << (log_n - 1)) + c];
+            const u64 p = i >> (g.log_n - 1);
+            reinterpret_cast<ulonglong2 *>(last)[i] = reinterpret_cast<const ulonglong2 *>(g.in)[rs_in(g, p, g.L - 1) + c];
         }
     }
 
@@ -391,12 +402,15 @@ namespace cat
     }
 
     cat_status launch_rescale(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t size, uint32_t batch,
-                              hipStream_t s)
+                              size_t in_stride, size_t out_stride, hipStream_t s)
     {
         const size_t N = ctx->n;
         const u64 polys = (u64)batch * size;
         const size_t w_last = (size_t)polys * N, w_tmp = (size_t)polys * (L - 1) * N;
-        const bool alias = (const u64 *)out == in;
+        // outputs overlap not-yet-read inputs whenever the two batches share memory
+        const u64 *in_end = in + (size_t)(batch ? batch - 1 : 0) * in_stride + (size_t)size * L * N;
+        const u64 *out_end = out + (size_t)(batch ? batch - 1 : 0) * out_stride + (size_t)size * (L - 1) * N;
+        const bool alias = !(out_end <= in || in_end <= out);
         const bool ckks = ctx->scheme != CAT_SCHEME_BFV;
         u64 *ws = (u64 *)workspace(ctx, (w_last + 2 * w_tmp) * sizeof(u64));
         if (!ws)
@@ -413,13 +427,16 @@ namespace cat
         g.L = L;
         g.k = ctx->k;
         g.log_n = ctx->log_n;
+        g.size = size;
+        g.in_stride2 = in_stride / 2;
+        g.out_stride2 = alias ? (u64)size * (L - 1) * N / 2 : out_stride / 2;
         g.last_stride2 = N / 2;
         g.total2 = w_tmp / 2;
         if (g.total2 == 0)
             return CAT_OK;
         if (ckks)
         {
-            hipLaunchKernelGGL(gather_last_kernel, dim3(grid_for(w_last / 2)), dim3(256), 0, s, in, last, L, ctx->log_n,
+            hipLaunchKernelGGL(gather_last_kernel, dim3(grid_for(w_last / 2)), dim3(256), 0, s, g, last,
                                (u64)w_last / 2);
             CAT_HIP(hipGetLastError());
             LimbMap ml{};
@@ -441,7 +458,8 @@ namespace cat
             CAT_HIP(hipGetLastError());
         }
         if (alias)
-            CAT_HIP(hipMemcpyAsync(out, stage, w_tmp * sizeof(u64), hipMemcpyDeviceToDevice, s));
+            CAT_HIP(hipMemcpy2DAsync(out, out_stride * sizeof(u64), stage, (size_t)size * (L - 1) * N * sizeof(u64),
+                                     (size_t)size * (L - 1) * N * sizeof(u64), batch, hipMemcpyDeviceToDevice, s));
         return CAT_OK;
     }
 } // namespace cat

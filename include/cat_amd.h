@@ -146,6 +146,11 @@ cat_status cat_relinearize(cat_ctx *ctx, uint64_t *d_ct3, const uint64_t *d_key,
  * (:1271) stays with the caller. */
 cat_status cat_rescale(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t size,
                        uint32_t batch, cat_stream s);
+/* Same, for batches whose ciphertexts are not back to back: in_stride / out_stride are the words
+ * between consecutive ciphertexts (e.g. 3*L*N right after cat_relinearize, whose "resize to 2",
+ * evaluator.cpp:1191, leaves the third polynomial in place). */
+cat_status cat_rescale_strided(cat_ctx *ctx, const uint64_t *d_in, size_t in_stride, uint64_t *d_out,
+                               size_t out_stride, uint32_t L, uint32_t size, uint32_t batch, cat_stream s);
 /* Evaluator::mod_switch_drop_to_next (evaluator.cpp:1282-1345): drop the last limb of every poly. */
 cat_status cat_mod_drop(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t size,
                         uint32_t batch, cat_stream s);
