@@ -166,6 +166,37 @@ class Context:
         _check(self.lib.cat_bfv_multiply(self.h, self._p(x), self._p(y), self._p(out), L, b, self._stream()))
         return out
 
+    # -- BEHZ pieces (util/rns.cpp:903-1131), one level with L limbs ------------------------------------
+    def bfv_base_Bsk(self, L: int):
+        n = self.lib.cat_bfv_base_Bsk_size(self.h, L)
+        out = (C.c_uint64 * max(n, 1))()
+        _check(self.lib.cat_bfv_base_Bsk(self.h, L, out))
+        return [int(out[i]) for i in range(n)]
+
+    def _piece(self, fn, x, L, in_limbs, out_limbs):
+        assert x.shape[-2] == in_limbs, (x.shape, in_limbs)
+        npoly = x.numel() // (in_limbs * self.n)
+        out = torch.empty(tuple(x.shape[:-2]) + (out_limbs, self.n), dtype=torch.int64, device=x.device)
+        _check(fn(self.h, self._p(x), self._p(out), L, npoly, self._stream()))
+        return out
+
+    def fastbconv_m_tilde(self, x, L):
+        """[..., L, N] in base q -> [..., |Bsk| + 1, N] in Bsk U {m_tilde}"""
+        bsk = self.lib.cat_bfv_base_Bsk_size(self.h, L)
+        return self._piece(self.lib.cat_fastbconv_m_tilde, x, L, L, bsk + 1)
+
+    def sm_mrq(self, x, L):
+        bsk = self.lib.cat_bfv_base_Bsk_size(self.h, L)
+        return self._piece(self.lib.cat_sm_mrq, x, L, bsk + 1, bsk)
+
+    def fast_floor(self, x, L):
+        bsk = self.lib.cat_bfv_base_Bsk_size(self.h, L)
+        return self._piece(self.lib.cat_fast_floor, x, L, L + bsk, bsk)
+
+    def fastbconv_sk(self, x, L):
+        bsk = self.lib.cat_bfv_base_Bsk_size(self.h, L)
+        return self._piece(self.lib.cat_fastbconv_sk, x, L, bsk, L)
+
     def switch_key(self, enc, target, key):
         """enc: [batch, 2, L, N] in place; target: [batch, L, N]; key: [k-1, 2, k, N]"""
         b, _, L, _ = enc.shape

@@ -1,11 +1,362 @@
-// BFV BEHZ multiplication (Evaluator::bfv_multiply, evaluator.cpp:395-567; util/rns.cpp:418-463, 903-1131).
+// BFV BEHZ multiplication (Evaluator::bfv_multiply, evaluator.cpp:395-567) and the RNSTool pieces it is
+// made of (util/rns.cpp: BaseConverter::fast_convert_array :418-463, RNSTool::initialize :578-787,
+// fastbconv_sk :903-979, sm_mrq :981-1041, fast_floor :1043-1090, fastbconv_m_tilde :1092-1131).
+//
+// Bases of a level with L limbs (rns.cpp:607-635): q = primes[0..L); the 61-bit auxiliary primes
+// get_primes(2N, 61, |B| + 2) = {m_sk, gamma, B_0, B_1, ...}; Bsk = B U {m_sk}; m_tilde = 2^32.
+// The context holds the descending 61-bit list once (moduli k.., capi.cpp), so every level's bases are
+// prefixes of it: m_sk = modulus k, B_i = modulus k + 2 + i.
+//
+// All conversions are per-coefficient small dense mat-vecs: one thread per coefficient stages the
+// |ibase| scaled residues x_i * (q/q_i)^-1 mod q_i in LDS ([limb][thread], conflict-free) and then forms
+// each output residue as a 128-bit dot product with one Barrett-128 (the reference reduces every 16
+// terms, uintarithsmallmod.cpp:110-173; the canonical result is the same).
 #include "context.hpp"
+
+#include <cstring>
+
+namespace
+{
+    constexpr u64 MT = 1ull << 32; // m_tilde (rns.cpp:635)
+
+    struct BconvArgs
+    {
+        const u64 *in;   // [polys][in_limbs_total][N]; the conversion reads limbs 0..isz-1
+        u64 *out;        // [polys][out_limbs_total][N]; the conversion writes limbs out_off..out_off+osz-1
+        u64 *mt_out;     // optional: limb index mt_limb of `out` receives the residue modulo 2^32
+        const DevMod *mods;
+        const MulOp *premul;  // [isz] or nullptr: x_i <- x_i * premul_i mod q_i first
+        const MulOp *inv_punc; // [isz]
+        const u64 *matrix;    // [osz][isz]
+        const u64 *mt_matrix; // [isz] or nullptr
+        LimbMap imap, omap;
+        u32 isz, osz, log_n;
+        u64 in_stride, out_stride; // words between consecutive polys
+        u32 out_off, mt_limb;
+        u64 total; // polys * N
+    };
+
+    __global__ __launch_bounds__(256) void bconv_kernel(BconvArgs g)
+    {
+        extern __shared__ u64 stage[]; // [isz][256]
+        const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+        if (i >= g.total)
+            return;
+        const u32 c = (u32)(i & ((1u << g.log_n) - 1));
+        const u64 p = i >> g.log_n;
+        const u64 *src = g.in + p * g.in_stride + c;
+        for (u32 j = 0; j < g.isz; ++j)
+        {
+            const u64 q = g.mods[g.imap.id[j]].q;
+            u64 x = src[(u64)j << g.log_n];
+            if (g.premul)
+                x = mul_shoup(x, g.premul[j].op, g.premul[j].quo, q);
+            stage[j * 256 + threadIdx.x] = mul_shoup(x, g.inv_punc[j].op, g.inv_punc[j].quo, q);
+        }
+        u64 *dst = g.out + p * g.out_stride + c;
+        for (u32 o = 0; o < g.osz; ++o)
+        {
+            const DevMod m = g.mods[g.omap.id[o]];
+            const u64 *row = g.matrix + (u64)o * g.isz;
+            u64 lo = 0, hi = 0;
+            for (u32 j = 0; j < g.isz; ++j)
+                mac128(lo, hi, stage[j * 256 + threadIdx.x], row[j]);
+            dst[(u64)(g.out_off + o) << g.log_n] = barrett128(lo, hi, m.q, m.ratio0, m.ratio1);
+        }
+        if (g.mt_matrix)
+        {
+            u64 acc = 0;
+            for (u32 j = 0; j < g.isz; ++j)
+                acc += stage[j * 256 + threadIdx.x] * g.mt_matrix[j];
+            dst[(u64)g.mt_limb << g.log_n] = acc & (MT - 1);
+        }
+    }
+
+    struct PieceArgs
+    {
+        const u64 *in;
+        u64 *out;
+        const DevMod *mods;
+        const MulOp *c0; // per-limb constants (meaning depends on the kernel)
+        const MulOp *c1;
+        const MulOp *c2;
+        LimbMap map;
+        u32 n_limbs, log_n, aux_limb;
+        u64 in_stride, out_stride;
+        u64 k0; // scalar constant
+        MulOp k1;
+        u64 total; // polys * n_limbs * N
+    };
+
+    // sm_mrq (rns.cpp:981-1041): in [polys][Bsk+1][N] (last limb modulo m_tilde) -> out [polys][Bsk][N]
+    //   r = in_mt * (-q^-1 mod m_tilde) mod m_tilde; r >= m_tilde/2 -> r += m_i - m_tilde;
+    //   out_i = (r * (q mod m_i) + in_i) * m_tilde^-1 mod m_i         c0 = q mod m_i, c1 = m_tilde^-1 mod m_i
+    __global__ __launch_bounds__(256) void sm_mrq_kernel(PieceArgs g)
+    {
+        const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+        if (i >= g.total)
+            return;
+        const u32 c = (u32)(i & ((1u << g.log_n) - 1));
+        const u64 r = i >> g.log_n;
+        const u32 j = (u32)(r % g.n_limbs);
+        const u64 p = r / g.n_limbs;
+        const DevMod m = g.mods[g.map.id[j]];
+        const u64 *src = g.in + p * g.in_stride + c;
+        u64 t = (src[(u64)g.n_limbs << g.log_n] * g.k0) & (MT - 1);
+        if (t >= (MT >> 1))
+            t += m.q - MT;
+        const u64 a = mul_shoup(t, g.c0[j].op, g.c0[j].quo, m.q);
+        const u64 b = barrett64(src[(u64)j << g.log_n], m.q, m.ratio1);
+        g.out[p * g.out_stride + ((u64)j << g.log_n) + c] = mul_shoup(add_mod(a, b, m.q), g.c1[j].op, g.c1[j].quo, m.q);
+    }
+
+    // fast_floor tail (rns.cpp:1070-1088): conv = FastBConv_{q->Bsk}(in_q) already sits in `out`;
+    //   out_i = (in_Bsk_i [* t] + (m_i - conv_i)) * q^-1 mod m_i       c0 = q^-1 mod m_i, c1 = t mod m_i or null
+    // `in` points at the Bsk part of the input.
+    __global__ __launch_bounds__(256) void floor_finish_kernel(PieceArgs g)
+    {
+        const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+        if (i >= g.total)
+            return;
+        const u32 c = (u32)(i & ((1u << g.log_n) - 1));
+        const u64 r = i >> g.log_n;
+        const u32 j = (u32)(r % g.n_limbs);
+        const u64 p = r / g.n_limbs;
+        const u64 q = g.mods[g.map.id[j]].q;
+        u64 x = g.in[p * g.in_stride + ((u64)j << g.log_n) + c];
+        if (g.c1)
+            x = mul_shoup(x, g.c1[j].op, g.c1[j].quo, q);
+        u64 *o = g.out + p * g.out_stride + ((u64)j << g.log_n) + c;
+        *o = mul_shoup(x + (q - *o), g.c0[j].op, g.c0[j].quo, q);
+    }
+
+    // fastbconv_sk tail (rns.cpp:930-977): `out` holds [polys][L + 1][N]: FastBConv_{B->q} in limbs 0..L-1
+    // and FastBConv_{B->m_sk} in limb L (aux_limb); in_sk is limb |B| of the input.
+    //   alpha = (conv_sk + (m_sk - in_sk)) * B^-1 mod m_sk                         k1 = B^-1 mod m_sk
+    //   alpha > m_sk/2 ? out_i += (m_sk - alpha) * (B mod q_i) : out_i += alpha * (-B mod q_i)   c0 = B, c1 = -B
+    // result -> res [polys][L][N]
+    __global__ __launch_bounds__(256) void sk_finish_kernel(PieceArgs g, u64 *res, u64 res_stride, u32 in_sk_limb,
+                                                             u32 msk_id)
+    {
+        const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+        if (i >= g.total)
+            return;
+        const u32 c = (u32)(i & ((1u << g.log_n) - 1));
+        const u64 r = i >> g.log_n;
+        const u32 j = (u32)(r % g.n_limbs);
+        const u64 p = r / g.n_limbs;
+        const u64 msk = g.mods[msk_id].q;
+        const u64 q = g.mods[g.map.id[j]].q;
+        const u64 *conv = g.out + p * g.out_stride + c;
+        const u64 in_sk = g.in[p * g.in_stride + ((u64)in_sk_limb << g.log_n) + c];
+        const u64 alpha = mul_shoup(conv[(u64)g.aux_limb << g.log_n] + (msk - in_sk), g.k1.op, g.k1.quo, msk);
+        const u64 cur = barrett64(conv[(u64)j << g.log_n], q, g.mods[g.map.id[j]].ratio1);
+        u64 v;
+        if (alpha > (msk >> 1))
+            v = mul_shoup(neg_mod(alpha, msk), g.c0[j].op, g.c0[j].quo, q);
+        else
+            v = mul_shoup(alpha, g.c1[j].op, g.c1[j].quo, q);
+        res[p * res_stride + ((u64)j << g.log_n) + c] = add_mod(v, cur, q);
+    }
+
+    // (x0,x1) (x) (y0,y1) over an arbitrary limb list; inputs may be lazy (< 4q): evaluator.cpp:497-541
+    struct TensorMapArgs
+    {
+        const u64 *x; // [batch][..] poly 0, 1 at x, x + poly
+        const u64 *y;
+        u64 *out; // [batch][3][nl][N]
+        const DevMod *mods;
+        LimbMap map;
+        u32 n_limbs, log_n;
+        u64 in_stride; // words between consecutive batch elements of x and of y
+        u64 total;     // batch * nl * N
+    };
+
+    __global__ __launch_bounds__(256) void tensor_map_kernel(TensorMapArgs g)
+    {
+        const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+        if (i >= g.total)
+            return;
+        const u64 poly = (u64)g.n_limbs << g.log_n;
+        const u64 b = i / poly, off = i % poly;
+        const DevMod m = g.mods[g.map.id[off >> g.log_n]];
+        const u64 *x = g.x + b * g.in_stride + off, *y = g.y + b * g.in_stride + off;
+        const u64 x0 = x[0], x1 = x[poly], y0 = y[0], y1 = y[poly];
+        u64 *o = g.out + b * 3 * poly + off;
+        o[0] = mul_mod(x0, y0, m.q, m.ratio0, m.ratio1);
+        o[poly] = add_mod(mul_mod(x1, y0, m.q, m.ratio0, m.ratio1), mul_mod(x0, y1, m.q, m.ratio0, m.ratio1), m.q);
+        o[2 * poly] = mul_mod(x1, y1, m.q, m.ratio0, m.ratio1);
+    }
+
+    u32 blocks_for(u64 items)
+    {
+        return (u32)((items + 255) / 256);
+    }
+
+    MulOp mk(const cat::HostMod &m, u64 v)
+    {
+        v %= m.q;
+        return MulOp{ v, m.shoup(v) };
+    }
+} // namespace
 
 namespace cat
 {
+    // RNSTool::initialize (util/rns.cpp:578-787) for the level with L limbs; device tables in one blob.
+    static cat_status build_level(cat_ctx *ctx, uint32_t L)
+    {
+        BfvLevel &lv = ctx->bfv[L];
+        const uint32_t k = ctx->k;
+        std::vector<u64> q(L);
+        for (uint32_t i = 0; i < L; ++i)
+            q[i] = ctx->hmods[i].q;
+        const std::vector<u64> prod_q = mp_product(q, SIZE_MAX);
+        // rns.cpp:607-615: |B| = L, one more when 32 + bits(t) + bits(q) >= 61 L + 61
+        int t_bits = 64 - __builtin_clzll(ctx->plain_modulus);
+        uint32_t B = L;
+        if (32 + t_bits + mp_bits(prod_q) >= 61 * (int)L + 61)
+            B++;
+        if (k + 2 + B > ctx->n_mod)
+            return fail(CAT_ERR_LOGIC, "invalid rns bases");
+        lv.L = L;
+        lv.B = B;
+        lv.Bsk = B + 1;
+        lv.idx_msk = k;
+        std::memset(&lv.map_q, 0, sizeof(LimbMap));
+        std::memset(&lv.map_Bsk, 0, sizeof(LimbMap));
+        for (uint32_t i = 0; i < L; ++i)
+            lv.map_q.id[i] = (unsigned char)i;
+        for (uint32_t i = 0; i < B; ++i)
+            lv.map_Bsk.id[i] = (unsigned char)(k + 2 + i);
+        lv.map_Bsk.id[B] = (unsigned char)k;
+        auto hm = [&](uint32_t id) -> const HostMod & { return ctx->hmods[id]; };
+        std::vector<u64> bvals(B);
+        for (uint32_t i = 0; i < B; ++i)
+            bvals[i] = hm(k + 2 + i).q;
+        const std::vector<u64> prod_B = mp_product(bvals, SIZE_MAX);
+
+        std::vector<u64> blob;
+        auto put_ops = [&](const std::vector<MulOp> &v) {
+            size_t off = blob.size();
+            for (const MulOp &o : v)
+            {
+                blob.push_back(o.op);
+                blob.push_back(o.quo);
+            }
+            return off;
+        };
+        auto put_words = [&](const std::vector<u64> &v) {
+            size_t off = blob.size();
+            blob.insert(blob.end(), v.begin(), v.end());
+            if (blob.size() & 1)
+                blob.push_back(0); // keep MulOp tables 16-byte aligned
+            return off;
+        };
+        std::vector<MulOp> ops;
+        std::vector<u64> words;
+        u64 inv = 0;
+
+        // base q: (q/q_i)^-1 mod q_i, m_tilde mod q_i, t mod q_i, B mod q_i, -B mod q_i
+        std::vector<std::vector<u64>> punc_q(L), punc_B(B);
+        for (uint32_t i = 0; i < L; ++i)
+            punc_q[i] = mp_product(q, i);
+        for (uint32_t i = 0; i < B; ++i)
+            punc_B[i] = mp_product(bvals, i);
+        ops.clear();
+        for (uint32_t i = 0; i < L; ++i)
+        {
+            if (!invert_mod(mp_mod(punc_q[i], q[i]), q[i], inv))
+                return fail(CAT_ERR_LOGIC, "invalid rns bases");
+            ops.push_back(mk(hm(i), inv));
+        }
+        lv.o_inv_punc_q = put_ops(ops);
+        ops.clear();
+        for (uint32_t i = 0; i < L; ++i)
+            ops.push_back(mk(hm(i), MT));
+        lv.o_mtilde_q = put_ops(ops);
+        ops.clear();
+        for (uint32_t i = 0; i < L; ++i)
+            ops.push_back(mk(hm(i), ctx->plain_modulus));
+        lv.o_t_q = put_ops(ops);
+        ops.clear();
+        for (uint32_t i = 0; i < L; ++i)
+            ops.push_back(mk(hm(i), mp_mod(prod_B, q[i])));
+        lv.o_prodB_q = put_ops(ops);
+        ops.clear();
+        for (uint32_t i = 0; i < L; ++i)
+            ops.push_back(mk(hm(i), q[i] - mp_mod(prod_B, q[i])));
+        lv.o_negprodB_q = put_ops(ops);
+        // q -> Bsk matrix [Bsk][L], q -> m_tilde [L]
+        words.clear();
+        for (uint32_t o = 0; o < lv.Bsk; ++o)
+            for (uint32_t i = 0; i < L; ++i)
+                words.push_back(mp_mod(punc_q[i], hm(lv.map_Bsk.id[o]).q));
+        lv.o_q_to_Bsk = put_words(words);
+        words.clear();
+        for (uint32_t i = 0; i < L; ++i)
+            words.push_back(mp_mod(punc_q[i], MT));
+        lv.o_q_to_mt = put_words(words);
+        // base B: (B/b_i)^-1 mod b_i; B -> q U {m_sk} matrix [L + 1][B]
+        ops.clear();
+        for (uint32_t i = 0; i < B; ++i)
+        {
+            if (!invert_mod(mp_mod(punc_B[i], bvals[i]), bvals[i], inv))
+                return fail(CAT_ERR_LOGIC, "invalid rns bases");
+            ops.push_back(mk(hm(k + 2 + i), inv));
+        }
+        lv.o_inv_punc_B = put_ops(ops);
+        words.clear();
+        for (uint32_t o = 0; o < L; ++o)
+            for (uint32_t i = 0; i < B; ++i)
+                words.push_back(mp_mod(punc_B[i], q[o]));
+        for (uint32_t i = 0; i < B; ++i)
+            words.push_back(mp_mod(punc_B[i], hm(k).q));
+        lv.o_B_to_q = put_words(words);
+        lv.o_B_to_msk = lv.o_B_to_q + (size_t)L * B;
+        // Bsk: q mod m_i, m_tilde^-1 mod m_i, q^-1 mod m_i, t mod m_i
+        std::vector<MulOp> pq, imt, iq, tb;
+        for (uint32_t i = 0; i < lv.Bsk; ++i)
+        {
+            const HostMod &m = hm(lv.map_Bsk.id[i]);
+            const u64 qm = mp_mod(prod_q, m.q);
+            pq.push_back(mk(m, qm));
+            if (!invert_mod(MT % m.q, m.q, inv))
+                return fail(CAT_ERR_LOGIC, "invalid rns bases");
+            imt.push_back(mk(m, inv));
+            if (!invert_mod(qm, m.q, inv))
+                return fail(CAT_ERR_LOGIC, "invalid rns bases");
+            iq.push_back(mk(m, inv));
+            tb.push_back(mk(m, ctx->plain_modulus));
+        }
+        lv.o_prod_q_Bsk = put_ops(pq);
+        lv.o_inv_mt_Bsk = put_ops(imt);
+        lv.o_inv_q_Bsk = put_ops(iq);
+        lv.o_t_Bsk = put_ops(tb);
+        // scalars
+        if (!invert_mod(mp_mod(prod_q, MT), MT, inv))
+            return fail(CAT_ERR_LOGIC, "invalid rns bases");
+        lv.neg_inv_q_mt = (MT - inv) & (MT - 1);
+        if (!invert_mod(mp_mod(prod_B, hm(k).q), hm(k).q, inv))
+            return fail(CAT_ERR_LOGIC, "invalid rns bases");
+        lv.inv_B_msk = mk(hm(k), inv);
+
+        CAT_HIP(hipMalloc((void **)&lv.d_blob, blob.size() * sizeof(u64)));
+        CAT_HIP(hipMemcpy(lv.d_blob, blob.data(), blob.size() * sizeof(u64), hipMemcpyHostToDevice));
+        lv.ready = true;
+        return CAT_OK;
+    }
+
     cat_status build_bfv_levels(cat_ctx *ctx)
     {
         ctx->bfv.assign(ctx->k + 1, BfvLevel{});
+        // data levels have 1 .. max(1, k-1) limbs (context.cu:607-637); L = k exists only when k == 1
+        const uint32_t top = ctx->k > 1 ? ctx->k - 1 : 1;
+        for (uint32_t L = 1; L <= top; ++L)
+        {
+            cat_status st = build_level(ctx, L);
+            if (st != CAT_OK)
+                return st;
+        }
         return CAT_OK;
     }
 
@@ -18,12 +369,296 @@ namespace cat
     }
 } // namespace cat
 
+namespace
+{
+    using namespace cat;
+
+    const MulOp *ops_at(const BfvLevel &lv, size_t off)
+    {
+        return reinterpret_cast<const MulOp *>(lv.d_blob + off);
+    }
+
+    cat_status level_of(cat_ctx *ctx, uint32_t L, const BfvLevel **out)
+    {
+        if (!ctx)
+            return fail(CAT_ERR_INVALID_ARG, "ctx");
+        CAT_HIP(hipSetDevice(ctx->device));
+        if (ctx->scheme != CAT_SCHEME_BFV)
+            return fail(CAT_ERR_LOGIC, "unsupported scheme");
+        if (L == 0 || L >= ctx->bfv.size() || !ctx->bfv[L].ready)
+            return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+        *out = &ctx->bfv[L];
+        return CAT_OK;
+    }
+
+    // FastBConv q -> Bsk (+ m_tilde when mt_limb_valid): in [polys][in_limbs][N] -> out limbs 0..Bsk-1 (+ Bsk)
+    cat_status conv_q_to_Bsk(cat_ctx *ctx, const BfvLevel &lv, const u64 *in, u64 in_stride, u64 *out, u64 out_stride,
+                             const MulOp *premul, bool with_mt, u64 polys, hipStream_t s)
+    {
+        BconvArgs g{};
+        g.in = in;
+        g.out = out;
+        g.mods = ctx->d_mods;
+        g.premul = premul;
+        g.inv_punc = ops_at(lv, lv.o_inv_punc_q);
+        g.matrix = lv.d_blob + lv.o_q_to_Bsk;
+        g.mt_matrix = with_mt ? lv.d_blob + lv.o_q_to_mt : nullptr;
+        g.imap = lv.map_q;
+        g.omap = lv.map_Bsk;
+        g.isz = lv.L;
+        g.osz = lv.Bsk;
+        g.log_n = ctx->log_n;
+        g.in_stride = in_stride;
+        g.out_stride = out_stride;
+        g.out_off = 0;
+        g.mt_limb = lv.Bsk;
+        g.total = polys << ctx->log_n;
+        if (g.total == 0)
+            return CAT_OK;
+        hipLaunchKernelGGL(bconv_kernel, dim3(blocks_for(g.total)), dim3(256), g.isz * 256 * sizeof(u64), s, g);
+        CAT_HIP(hipGetLastError());
+        return CAT_OK;
+    }
+
+    cat_status run_sm_mrq(cat_ctx *ctx, const BfvLevel &lv, const u64 *in, u64 in_stride, u64 *out, u64 out_stride,
+                          u64 polys, hipStream_t s)
+    {
+        PieceArgs g{};
+        g.in = in;
+        g.out = out;
+        g.mods = ctx->d_mods;
+        g.c0 = ops_at(lv, lv.o_prod_q_Bsk);
+        g.c1 = ops_at(lv, lv.o_inv_mt_Bsk);
+        g.map = lv.map_Bsk;
+        g.n_limbs = lv.Bsk;
+        g.log_n = ctx->log_n;
+        g.in_stride = in_stride;
+        g.out_stride = out_stride;
+        g.k0 = lv.neg_inv_q_mt;
+        g.total = (polys * lv.Bsk) << ctx->log_n;
+        if (g.total == 0)
+            return CAT_OK;
+        hipLaunchKernelGGL(sm_mrq_kernel, dim3(blocks_for(g.total)), dim3(256), 0, s, g);
+        CAT_HIP(hipGetLastError());
+        return CAT_OK;
+    }
+
+    // in_q / in_B: the q part and the Bsk part of the input (each with its own poly stride)
+    cat_status run_fast_floor(cat_ctx *ctx, const BfvLevel &lv, const u64 *in_q, u64 in_q_stride, const u64 *in_B,
+                              u64 in_B_stride, u64 *out, u64 out_stride, bool times_t, u64 polys, hipStream_t s)
+    {
+        cat_status st = conv_q_to_Bsk(ctx, lv, in_q, in_q_stride, out, out_stride,
+                                      times_t ? ops_at(lv, lv.o_t_q) : nullptr, false, polys, s);
+        if (st != CAT_OK)
+            return st;
+        PieceArgs g{};
+        g.in = in_B;
+        g.out = out;
+        g.mods = ctx->d_mods;
+        g.c0 = ops_at(lv, lv.o_inv_q_Bsk);
+        g.c1 = times_t ? ops_at(lv, lv.o_t_Bsk) : nullptr;
+        g.map = lv.map_Bsk;
+        g.n_limbs = lv.Bsk;
+        g.log_n = ctx->log_n;
+        g.in_stride = in_B_stride;
+        g.out_stride = out_stride;
+        g.total = (polys * lv.Bsk) << ctx->log_n;
+        if (g.total == 0)
+            return CAT_OK;
+        hipLaunchKernelGGL(floor_finish_kernel, dim3(blocks_for(g.total)), dim3(256), 0, s, g);
+        CAT_HIP(hipGetLastError());
+        return CAT_OK;
+    }
+
+    // in [polys][Bsk][N] -> out [polys][L][N] (out_stride words apart); conv: scratch [polys][L+1][N]
+    cat_status run_fastbconv_sk(cat_ctx *ctx, const BfvLevel &lv, const u64 *in, u64 in_stride, u64 *conv, u64 *out,
+                                u64 out_stride, u64 polys, hipStream_t s)
+    {
+        const u64 N = ctx->n;
+        BconvArgs b{};
+        b.in = in;
+        b.out = conv;
+        b.mods = ctx->d_mods;
+        b.inv_punc = ops_at(lv, lv.o_inv_punc_B);
+        b.matrix = lv.d_blob + lv.o_B_to_q;
+        b.imap = lv.map_Bsk; // first |B| entries are base B
+        b.omap = lv.map_q;
+        b.omap.id[lv.L] = (unsigned char)lv.idx_msk;
+        b.isz = lv.B;
+        b.osz = lv.L + 1;
+        b.log_n = ctx->log_n;
+        b.in_stride = in_stride;
+        b.out_stride = (u64)(lv.L + 1) * N;
+        b.total = polys << ctx->log_n;
+        if (b.total == 0)
+            return CAT_OK;
+        hipLaunchKernelGGL(bconv_kernel, dim3(blocks_for(b.total)), dim3(256), b.isz * 256 * sizeof(u64), s, b);
+        CAT_HIP(hipGetLastError());
+        PieceArgs g{};
+        g.in = in;
+        g.out = conv;
+        g.mods = ctx->d_mods;
+        g.c0 = ops_at(lv, lv.o_prodB_q);
+        g.c1 = ops_at(lv, lv.o_negprodB_q);
+        g.map = lv.map_q;
+        g.n_limbs = lv.L;
+        g.log_n = ctx->log_n;
+        g.aux_limb = lv.L;
+        g.in_stride = in_stride;
+        g.out_stride = (u64)(lv.L + 1) * N;
+        g.k1 = lv.inv_B_msk;
+        g.total = (polys * lv.L) << ctx->log_n;
+        hipLaunchKernelGGL(sk_finish_kernel, dim3(blocks_for(g.total)), dim3(256), 0, s, g, out, out_stride, lv.B,
+                           lv.idx_msk);
+        CAT_HIP(hipGetLastError());
+        return CAT_OK;
+    }
+} // namespace
+
 extern "C" {
-uint32_t cat_bfv_base_Bsk_size(const cat_ctx *, uint32_t) { return 0; }
-cat_status cat_bfv_base_Bsk(const cat_ctx *, uint32_t, uint64_t *) { return cat::fail(CAT_ERR_LOGIC, "unsupported scheme"); }
-cat_status cat_bfv_multiply(cat_ctx *, const uint64_t *, const uint64_t *, uint64_t *, uint32_t, uint32_t, cat_stream) { return cat::fail(CAT_ERR_LOGIC, "unsupported scheme"); }
-cat_status cat_fastbconv_m_tilde(cat_ctx *, const uint64_t *, uint64_t *, uint32_t, uint32_t, cat_stream) { return cat::fail(CAT_ERR_LOGIC, "unsupported scheme"); }
-cat_status cat_sm_mrq(cat_ctx *, const uint64_t *, uint64_t *, uint32_t, uint32_t, cat_stream) { return cat::fail(CAT_ERR_LOGIC, "unsupported scheme"); }
-cat_status cat_fast_floor(cat_ctx *, const uint64_t *, uint64_t *, uint32_t, uint32_t, cat_stream) { return cat::fail(CAT_ERR_LOGIC, "unsupported scheme"); }
-cat_status cat_fastbconv_sk(cat_ctx *, const uint64_t *, uint64_t *, uint32_t, uint32_t, cat_stream) { return cat::fail(CAT_ERR_LOGIC, "unsupported scheme"); }
+
+uint32_t cat_bfv_base_Bsk_size(const cat_ctx *ctx, uint32_t L)
+{
+    if (!ctx || L >= ctx->bfv.size() || !ctx->bfv[L].ready)
+        return 0;
+    return ctx->bfv[L].Bsk;
 }
+
+cat_status cat_bfv_base_Bsk(const cat_ctx *ctx, uint32_t L, uint64_t *out_moduli)
+{
+    if (!ctx || !out_moduli || L >= ctx->bfv.size() || !ctx->bfv[L].ready)
+        return fail(CAT_ERR_INVALID_ARG, "no BEHZ bases for this level");
+    const BfvLevel &lv = ctx->bfv[L];
+    for (uint32_t i = 0; i < lv.Bsk; ++i)
+        out_moduli[i] = ctx->hmods[lv.map_Bsk.id[i]].q;
+    return CAT_OK;
+}
+
+cat_status cat_fastbconv_m_tilde(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys,
+                                 cat_stream s)
+{
+    const BfvLevel *lv;
+    cat_status st = level_of(ctx, L, &lv);
+    if (st != CAT_OK)
+        return st;
+    if (n_polys && (!d_in || !d_out))
+        return fail(CAT_ERR_INVALID_ARG, "input");
+    return conv_q_to_Bsk(ctx, *lv, (const u64 *)d_in, (u64)L * ctx->n, (u64 *)d_out, (u64)(lv->Bsk + 1) * ctx->n,
+                         ops_at(*lv, lv->o_mtilde_q), true, n_polys, (hipStream_t)s);
+}
+
+cat_status cat_sm_mrq(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys, cat_stream s)
+{
+    const BfvLevel *lv;
+    cat_status st = level_of(ctx, L, &lv);
+    if (st != CAT_OK)
+        return st;
+    if (n_polys && (!d_in || !d_out))
+        return fail(CAT_ERR_INVALID_ARG, "input");
+    return run_sm_mrq(ctx, *lv, (const u64 *)d_in, (u64)(lv->Bsk + 1) * ctx->n, (u64 *)d_out, (u64)lv->Bsk * ctx->n,
+                      n_polys, (hipStream_t)s);
+}
+
+cat_status cat_fast_floor(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys,
+                          cat_stream s)
+{
+    const BfvLevel *lv;
+    cat_status st = level_of(ctx, L, &lv);
+    if (st != CAT_OK)
+        return st;
+    if (n_polys && (!d_in || !d_out))
+        return fail(CAT_ERR_INVALID_ARG, "input");
+    const u64 stride = (u64)(L + lv->Bsk) * ctx->n;
+    return run_fast_floor(ctx, *lv, (const u64 *)d_in, stride, (const u64 *)d_in + (u64)L * ctx->n, stride,
+                          (u64 *)d_out, (u64)lv->Bsk * ctx->n, false, n_polys, (hipStream_t)s);
+}
+
+cat_status cat_fastbconv_sk(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys,
+                            cat_stream s)
+{
+    const BfvLevel *lv;
+    cat_status st = level_of(ctx, L, &lv);
+    if (st != CAT_OK)
+        return st;
+    if (n_polys && (!d_in || !d_out))
+        return fail(CAT_ERR_INVALID_ARG, "input");
+    u64 *conv = (u64 *)workspace(ctx, (size_t)n_polys * (L + 1) * ctx->n * sizeof(u64));
+    if (!conv)
+        return CAT_ERR_NOMEM;
+    return run_fastbconv_sk(ctx, *lv, (const u64 *)d_in, (u64)lv->Bsk * ctx->n, conv, (u64 *)d_out, (u64)L * ctx->n,
+                            n_polys, (hipStream_t)s);
+}
+
+cat_status cat_bfv_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, uint64_t *d_out, uint32_t L,
+                            uint32_t batch, cat_stream stream)
+{
+    const BfvLevel *lvp;
+    cat_status st = level_of(ctx, L, &lvp);
+    if (st != CAT_OK)
+        return st;
+    if (batch == 0)
+        return CAT_OK;
+    if (!d_x || !d_y || !d_out)
+        return fail(CAT_ERR_INVALID_ARG, "encrypted1 or encrypted2 is not valid");
+    if (d_out == d_x || d_out == d_y)
+        return fail(CAT_ERR_INVALID_ARG, "destination must not alias the inputs");
+    const BfvLevel &lv = *lvp;
+    hipStream_t s = (hipStream_t)stream;
+    const u64 N = ctx->n, Bsk = lv.Bsk, b = batch;
+    const u64 pq = (u64)L * N, pB = Bsk * N;
+    // workspace (words): inq [b][4][L][N] | inB [b][4][Bsk][N] | lift [b][4][Bsk+1][N] (reused as conv) |
+    //                    tq [b][3][L][N] | tB [b][3][Bsk][N] | fl [b][3][Bsk][N]
+    const size_t w_inq = b * 4 * pq, w_inB = b * 4 * pB, w_lift = b * 4 * (Bsk + 1) * N, w_tq = b * 3 * pq,
+                 w_tB = b * 3 * pB, w_fl = b * 3 * pB;
+    u64 *ws = (u64 *)workspace(ctx, (w_inq + w_inB + w_lift + w_tq + w_tB + w_fl) * sizeof(u64));
+    if (!ws)
+        return CAT_ERR_NOMEM;
+    u64 *inq = ws, *inB = inq + w_inq, *lift = inB + w_inB, *tq = lift + w_lift, *tB = tq + w_tq, *fl = tB + w_tB;
+    // steps (1)-(3), evaluator.cpp:452-490: per input polynomial, lazy NTT in q; lift to Bsk, lazy NTT in Bsk
+    CAT_HIP(hipMemcpy2DAsync(inq, 4 * pq * sizeof(u64), d_x, 2 * pq * sizeof(u64), 2 * pq * sizeof(u64), batch,
+                             hipMemcpyDeviceToDevice, s));
+    CAT_HIP(hipMemcpy2DAsync(inq + 2 * pq, 4 * pq * sizeof(u64), d_y, 2 * pq * sizeof(u64), 2 * pq * sizeof(u64), batch,
+                             hipMemcpyDeviceToDevice, s));
+    if ((st = conv_q_to_Bsk(ctx, lv, inq, pq, lift, (Bsk + 1) * N, ops_at(lv, lv.o_mtilde_q), true, b * 4, s)) != CAT_OK)
+        return st;
+    if ((st = run_sm_mrq(ctx, lv, lift, (Bsk + 1) * N, inB, pB, b * 4, s)) != CAT_OK)
+        return st;
+    if ((st = launch_ntt(ctx, true, inq, lv.map_q, L, batch * 4, true, s)) != CAT_OK)
+        return st;
+    if ((st = launch_ntt(ctx, true, inB, lv.map_Bsk, (uint32_t)Bsk, batch * 4, true, s)) != CAT_OK)
+        return st;
+    // step (4), :493-541
+    {
+        TensorMapArgs g{};
+        g.mods = ctx->d_mods;
+        g.log_n = ctx->log_n;
+        g.x = inq;
+        g.y = inq + 2 * pq;
+        g.out = tq;
+        g.map = lv.map_q;
+        g.n_limbs = L;
+        g.in_stride = 4 * pq;
+        g.total = b * pq;
+        hipLaunchKernelGGL(tensor_map_kernel, dim3(blocks_for(g.total)), dim3(256), 0, s, g);
+        g.x = inB;
+        g.y = inB + 2 * pB;
+        g.out = tB;
+        g.map = lv.map_Bsk;
+        g.n_limbs = (u32)Bsk;
+        g.in_stride = 4 * pB;
+        g.total = b * pB;
+        hipLaunchKernelGGL(tensor_map_kernel, dim3(blocks_for(g.total)), dim3(256), 0, s, g);
+        CAT_HIP(hipGetLastError());
+    }
+    // step (5), :545-546
+    if ((st = launch_ntt(ctx, false, tq, lv.map_q, L, batch * 3, true, s)) != CAT_OK)
+        return st;
+    if ((st = launch_ntt(ctx, false, tB, lv.map_Bsk, (uint32_t)Bsk, batch * 3, true, s)) != CAT_OK)
+        return st;
+    // steps (6)-(8), :549-566: multiply by t, fast_floor, fastbconv_sk
+    if ((st = run_fast_floor(ctx, lv, tq, pq, tB, pB, fl, pB, true, b * 3, s)) != CAT_OK)
+        return st;
+    return run_fastbconv_sk(ctx, lv, fl, pB, lift, (u64 *)d_out, pq, b * 3, s);
+}
+
+} // extern "C"

@@ -321,3 +321,89 @@ def test_rescale_reference_known_answers(cat, oracle):
         for j in range(2):
             assert (q[0] + exp[j] - int(res[j])) % q[0] <= tol
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------- BFV / BEHZ
+
+
+@pytest.mark.parametrize("log_n,bits,t", [(3, [30, 30, 31], 17), (12, [36, 36, 37], 65537), (11, [54], 1032193)])
+def test_behz_pieces_match_oracle(cat, oracle, log_n, bits, t):
+    """fastbconv_m_tilde / sm_mrq / fast_floor / fastbconv_sk (util/rns.cpp:903-1131) against the oracle's
+    RNSTool (itself pinned by tests/util/rns.cpp:460-853 in test_oracle_known_answers.py)."""
+    n = 1 << log_n
+    primes = oracle.coeff_modulus_create(n, bits)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_BFV, t)
+    top = len(primes) - 1 if len(primes) > 1 else 1
+    rng = np.random.default_rng(31 + log_n)
+    for L in range(1, top + 1):
+        tool = oracle.RNSTool(n, primes[:L], t)
+        bsk = tool.Bsk
+        assert ctx.bfv_base_Bsk(L) == bsk
+        polys = 3
+        xq = rand_limbs(rng, primes[:L], (polys,), n)
+        xq[0, :, 0] = 0
+        xq[0, :, 1] = np.array(primes[:L], dtype=np.uint64) - 1
+        got = host(ctx.fastbconv_m_tilde(dev(xq), L))
+        exp = np.stack([tool.fastbconv_m_tilde(xq[p].reshape(-1)).reshape(len(bsk) + 1, n) for p in range(polys)])
+        assert (got == exp).all(), f"fastbconv_m_tilde L={L}"
+        got = host(ctx.sm_mrq(dev(exp), L))
+        exp2 = np.stack([tool.sm_mrq(exp[p].reshape(-1)).reshape(len(bsk), n) for p in range(polys)])
+        assert (got == exp2).all(), f"sm_mrq L={L}"
+        xqb = rand_limbs(rng, primes[:L] + bsk, (polys,), n)
+        got = host(ctx.fast_floor(dev(xqb), L))
+        exp3 = np.stack([tool.fast_floor(xqb[p].reshape(-1)).reshape(len(bsk), n) for p in range(polys)])
+        assert (got == exp3).all(), f"fast_floor L={L}"
+        xb = rand_limbs(rng, bsk, (polys,), n)
+        got = host(ctx.fastbconv_sk(dev(xb), L))
+        exp4 = np.stack([tool.fastbconv_sk(xb[p].reshape(-1)).reshape(L, n) for p in range(polys)])
+        assert (got == exp4).all(), f"fastbconv_sk L={L}"
+    ctx.close()
+
+
+@pytest.mark.parametrize("log_n,bits,t", [(12, [36, 36, 37], 65537), (13, [43, 43, 44, 44, 44], 786433), (10, [27], 12289)])
+def test_bfv_multiply_relinearize_matches_oracle(cat, oracle, log_n, bits, t):
+    n = 1 << log_n
+    primes = oracle.coeff_modulus_create(n, bits)
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_BFV, t)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_BFV, t)
+    k = len(primes)
+    top = k - 1 if k > 1 else 1
+    batch = 2
+    for L in range(top, 0, -1):
+        x = np.stack([octx.uniform(L, 2, 70 + b + L) for b in range(batch)])
+        y = np.stack([octx.uniform(L, 2, 80 + b + L) for b in range(batch)])
+        got = ctx.bfv_multiply(dev(x), dev(y))
+        exp = np.stack([octx.bfv_multiply(x[b], y[b]) for b in range(batch)])
+        assert (host(got) == exp).all(), f"bfv_multiply L={L}"
+        if k > 1:
+            sk = octx.secret_key(11)
+            rk = octx.relin_key(sk, 12)
+            relin = host(ctx.relinearize(got, dev(rk)).contiguous())
+            assert (relin == np.stack([octx.relinearize(exp[b], rk) for b in range(batch)])).all()
+    with pytest.raises(RuntimeError):
+        c2 = cat.Context(log_n, primes, cat.SCHEME_CKKS)
+        try:
+            c2.bfv_multiply(dev(x), dev(y))
+        finally:
+            c2.close()
+    ctx.close()
+
+
+def test_bfv_config3_multiply_relinearize(cat, oracle):
+    """BASELINE config 3: BFV N=16384, BFVDefault(16384) = 9 primes / 438 bits (util/globals.cpp:52-59),
+    t = 786433 (examples/6_performance.cpp:980): multiply_inplace + relinearize_inplace."""
+    log_n, n, t = 14, 16384, 786433
+    primes = oracle.bfv_default(n)
+    assert len(primes) == 9
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_BFV, t)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_BFV, t)
+    L = 8
+    sk = octx.secret_key(21)
+    rk = octx.relin_key(sk, 22)
+    x, y = octx.uniform(L, 2, 23), octx.uniform(L, 2, 24)
+    got = ctx.bfv_multiply(dev(x[None]), dev(y[None]))
+    exp = octx.bfv_multiply(x, y)
+    assert (host(got)[0] == exp).all()
+    relin = host(ctx.relinearize(got, dev(rk)).contiguous())
+    assert (relin[0] == octx.relinearize(exp, rk)).all()
+    ctx.close()
