@@ -1,0 +1,105 @@
+"""Batch sharding of independent ciphertext operations over the GPUs of one node.
+
+The path shards without any data-path collective: ciphertext operations are independent units, so rank r
+of W takes a contiguous slice of the batch, holds its own replica of the read-only state (NTT tables inside
+its Context, relinearization / Galois keys) and never talks to the other ranks while computing.  RCCL over
+xGMI (torch.distributed backend "nccl" on ROCm) is used for exactly two things, both outside the steady
+state: broadcasting key material from the rank that loaded it, and (optionally) gathering results.
+
+The reference has no counterpart (single GPU, single process: no nccl/MPI anywhere under native/src,
+SURVEY.md 2a); this module is the MI355X-side addition that BASELINE config 5 asks for (8192 independent
+CKKS N=2^15 mul+relin, 1024 per GPU at 8 GPUs).  It is backend-agnostic so the same code is exercised on
+CPU with gloo in tests/test_sharding_gloo.py.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) slice of rank `rank`; the first n_items % world ranks get one extra item."""
+    if world <= 0 or not (0 <= rank < world) or n_items < 0:
+        raise ValueError("invalid shard request")
+    base, extra = divmod(n_items, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_sizes(n_items: int, world: int) -> List[int]:
+    return [shard_range(n_items, world, r)[1] - shard_range(n_items, world, r)[0] for r in range(world)]
+
+
+def world_info() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def broadcast_key(key: torch.Tensor, src: int = 0, bucket_bytes: int = 256 << 20) -> torch.Tensor:
+    """Replicates a key tensor ([k-1, 2, k, N] words) from `src` to every rank, in place.
+
+    One-to-all over xGMI is per-link bound (7 links x ~153 GB/s per GPU), so the key is sent in a few large
+    buckets rather than per limb: a 126 MB relinearization key (N=2^15, 16 primes) is one bucket, a 629 MB
+    Galois key (N=2^16, 25 primes) three."""
+    world, _ = world_info()
+    if world == 1:
+        return key
+    flat = key.view(-1)
+    step = max(1, bucket_bytes // flat.element_size())
+    for off in range(0, flat.numel(), step):
+        dist.broadcast(flat[off : off + step], src=src)
+    return key
+
+
+def gather_results(local: torch.Tensor, n_items: int, dst: Optional[int] = None) -> Optional[torch.Tensor]:
+    """Concatenates the per-rank result slices (dim 0) in rank order.
+
+    dst=None: every rank gets the full batch (all_gather); otherwise only rank `dst` (others return None).
+    Slices may differ by one item (shard_range), so shorter slices are padded for the collective."""
+    world, rank = world_info()
+    if world == 1:
+        return local
+    sizes = shard_sizes(n_items, world)
+    if local.shape[0] != sizes[rank]:
+        raise ValueError("local slice does not match shard_range")
+    width = max(sizes)
+    if local.shape[0] < width:
+        pad = torch.zeros((width - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    local = local.contiguous()
+    if dst is None:
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local)
+    else:
+        parts = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+        dist.gather(local, parts, dst=dst)
+        if rank != dst:
+            return None
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+def run_sharded(op: Callable[[int, int], torch.Tensor], n_items: int, gather: bool = True,
+                dst: Optional[int] = None) -> Optional[torch.Tensor]:
+    """Runs `op(begin, end)` on this rank's slice of an n_items batch and optionally gathers the results.
+
+    `op` is the single-GPU pipeline (e.g. Context.ckks_multiply + relinearize on items [begin, end)); there is
+    no communication inside it."""
+    world, rank = world_info()
+    begin, end = shard_range(n_items, world, rank)
+    local = op(begin, end)
+    if not gather:
+        return local
+    return gather_results(local, n_items, dst=dst)
+
+
+def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
+    """Timing helper for the bench contract: the slowest rank's time."""
+    world, _ = world_info()
+    if world == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
