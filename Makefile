@@ -7,7 +7,7 @@ HDR := include/cat_amd.h cat_amd/csrc/context.hpp cat_amd/csrc/host_math.hpp cat
 OBJ := $(patsubst cat_amd/csrc/%,build/%.o,$(SRC))
 LIB := cat_amd/lib/libcat_amd.so
 
-all: $(LIB) oracle
+all: $(LIB) oracle facade_test
 
 $(LIB): $(OBJ)
 	@mkdir -p cat_amd/lib
@@ -24,8 +24,14 @@ build/%.cpp.o: cat_amd/csrc/%.cpp $(HDR)
 oracle:
 	$(MAKE) -s -C oracle
 
+# C++ facade parity test (needs a GPU to run; plain g++: the facade only sees the C ABI)
+facade_test: tests/cpp/facade_test
+tests/cpp/facade_test: tests/cpp/test_facade.cpp cat_amd/host/seal_hip.hpp include/cat_amd.h $(LIB) oracle
+	g++ -std=c++17 -O2 -Wall $< -o $@ -Lcat_amd/lib -lcat_amd -Loracle -lseal_oracle \
+	    -Wl,-rpath,'$$ORIGIN/../../cat_amd/lib' -Wl,-rpath,'$$ORIGIN/../../oracle' -Wl,-rpath-link,/opt/rocm/lib
+
 clean:
 	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean facade_test

@@ -1,0 +1,805 @@
+// seal_hip.hpp -- C++ host facade over the C ABI (include/cat_amd.h) that keeps the reference's class and
+// function names for the hot path, so code written against Rayman96/CAT's seal::Evaluator /
+// seal::util::ntt_negacyclic_harvey keeps its shape.  Header-only; links against libcat_amd.so only.
+//
+// What is mirrored (paths relative to /root/reference/native/src/seal/):
+//   seal::util::ntt_negacyclic_harvey[_lazy], inverse_ntt_negacyclic_harvey[_lazy]   util/ntt.h:201-270
+//   seal::util::{add,sub,negate}_poly_coeffmod, dyadic_product_coeffmod               util/polyarithsmallmod.cuh:84-611
+//   seal::Ciphertext (size/coeff_modulus_size/is_ntt_form/scale, to_gpu/to_cpu)        ciphertext.cuh:356-385, 496-735
+//   seal::KSwitchKeys / RelinKeys / GaloisKeys (get_index, has_key)                   kswitchkeys.h:36-131, relinkeys.h:58-64, galoiskeys.h:48-50
+//   seal::Evaluator::{add,sub,negate,multiply,relinearize,rescale_to_next,mod_switch_to_next,
+//                     transform_{to,from}_ntt,apply_galois,rotate_vector,rotate_rows,complex_conjugate}_inplace
+//                                                                                      evaluator.h:88-1298
+// Differences that are deliberate: data lives on the device (the reference keeps a host array plus a
+// device shadow; here upload()/download() are the to_gpu()/to_cpu() of ciphertext.cuh:361-381); key
+// generation, encoding and encryption stay with the caller; errors are
+// the reference's exception types with the reference's messages, never exit().
+#pragma once
+
+#include "../../include/cat_amd.h"
+
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace seal
+{
+    enum class scheme_type : std::uint8_t
+    {
+        none = 0x0,
+        bfv = 0x1,
+        ckks = 0x2
+    };
+
+    namespace detail
+    {
+        // cat_status -> the exception the reference would have thrown (evaluator.cpp:2534-2573)
+        inline void check(cat_status st)
+        {
+            switch (st)
+            {
+            case CAT_OK:
+                return;
+            case CAT_ERR_INVALID_ARG:
+                throw std::invalid_argument(cat_last_error());
+            case CAT_ERR_LOGIC:
+                throw std::logic_error(cat_last_error());
+            case CAT_ERR_OUT_OF_RANGE:
+                throw std::out_of_range(cat_last_error());
+            case CAT_ERR_NOMEM:
+                throw std::bad_alloc();
+            default:
+                throw std::runtime_error(cat_last_error());
+            }
+        }
+    } // namespace detail
+
+    class EncryptionParameters
+    {
+    public:
+        explicit EncryptionParameters(scheme_type scheme) : scheme_(scheme)
+        {}
+        void set_poly_modulus_degree(std::size_t n)
+        {
+            n_ = n;
+        }
+        void set_coeff_modulus(const std::vector<std::uint64_t> &q)
+        {
+            q_ = q;
+        }
+        void set_plain_modulus(std::uint64_t t)
+        {
+            t_ = t;
+        }
+        scheme_type scheme() const noexcept
+        {
+            return scheme_;
+        }
+        std::size_t poly_modulus_degree() const noexcept
+        {
+            return n_;
+        }
+        const std::vector<std::uint64_t> &coeff_modulus() const noexcept
+        {
+            return q_;
+        }
+        std::uint64_t plain_modulus() const noexcept
+        {
+            return t_;
+        }
+
+    private:
+        scheme_type scheme_;
+        std::size_t n_ = 0;
+        std::vector<std::uint64_t> q_;
+        std::uint64_t t_ = 0;
+    };
+
+    // SEALContext for this path: the modulus chain, per-prime NTT tables and per-level RNS tools live in the
+    // device context (context.cu:292-356, 607-765).  A level is named by its number of limbs L: the key
+    // level has all k primes, the first data level k-1 (or 1 when k == 1), each next level one fewer.
+    class SEALContext
+    {
+    public:
+        explicit SEALContext(const EncryptionParameters &parms, int device = 0) : parms_(parms)
+        {
+            const std::size_t n = parms.poly_modulus_degree();
+            std::uint32_t log_n = 0;
+            while ((std::size_t(1) << log_n) < n)
+                ++log_n;
+            if (n == 0 || (std::size_t(1) << log_n) != n)
+                throw std::invalid_argument("poly_modulus_degree is invalid");
+            cat_ctx *h = nullptr;
+            detail::check(cat_ctx_create(log_n, parms.coeff_modulus().data(), (std::uint32_t)parms.coeff_modulus().size(),
+                                         (int)parms.scheme(), parms.plain_modulus(), device, &h));
+            h_.reset(h, [](cat_ctx *p) { cat_ctx_destroy(p); });
+        }
+        cat_ctx *handle() const noexcept
+        {
+            return h_.get();
+        }
+        const EncryptionParameters &parms() const noexcept
+        {
+            return parms_;
+        }
+        std::size_t poly_modulus_degree() const noexcept
+        {
+            return parms_.poly_modulus_degree();
+        }
+        std::size_t key_modulus_size() const noexcept
+        {
+            return parms_.coeff_modulus().size();
+        }
+        std::size_t first_level_size() const noexcept
+        {
+            const std::size_t k = key_modulus_size();
+            return k > 1 ? k - 1 : k;
+        }
+        bool using_keyswitching() const noexcept
+        {
+            return key_modulus_size() > 1;
+        }
+
+    private:
+        EncryptionParameters parms_;
+        std::shared_ptr<cat_ctx> h_;
+    };
+
+    // Device-resident ciphertext: size x coeff_modulus_size x N words, poly[limb][coeff] (ciphertext.cuh:423-434).
+    class Ciphertext
+    {
+    public:
+        Ciphertext() = default;
+        Ciphertext(const SEALContext &context, std::size_t coeff_modulus_size, std::size_t size = 2)
+        {
+            resize(context, coeff_modulus_size, size);
+        }
+        Ciphertext(const Ciphertext &o)
+        {
+            *this = o;
+        }
+        Ciphertext &operator=(const Ciphertext &o)
+        {
+            if (this == &o)
+                return *this;
+            ctx_ = o.ctx_;
+            n_ = o.n_;
+            is_ntt_form_ = o.is_ntt_form_;
+            scale_ = o.scale_;
+            reserve_words(o.words());
+            size_ = o.size_;
+            L_ = o.L_;
+            if (o.words())
+            {
+                // device-to-device through the staging entry points of the ABI
+                std::vector<std::uint64_t> tmp(o.words());
+                o.download(tmp.data());
+                upload(tmp.data());
+            }
+            return *this;
+        }
+        Ciphertext(Ciphertext &&o) noexcept
+        {
+            *this = std::move(o);
+        }
+        Ciphertext &operator=(Ciphertext &&o) noexcept
+        {
+            if (this != &o)
+            {
+                release();
+                ctx_ = std::move(o.ctx_);
+                d_ = o.d_;
+                cap_ = o.cap_;
+                size_ = o.size_;
+                L_ = o.L_;
+                n_ = o.n_;
+                is_ntt_form_ = o.is_ntt_form_;
+                scale_ = o.scale_;
+                o.d_ = nullptr;
+                o.cap_ = o.size_ = o.L_ = 0;
+            }
+            return *this;
+        }
+        ~Ciphertext()
+        {
+            release();
+        }
+
+        // Ciphertext::resize(context, parms_id, size) (ciphertext.cpp:76-107); contents are kept when the
+        // limb count is unchanged, exactly like the reference's resize of the backing array.
+        void resize(const SEALContext &context, std::size_t coeff_modulus_size, std::size_t size)
+        {
+            if (size < 2 && size != 0)
+                throw std::invalid_argument("invalid size");
+            if (coeff_modulus_size == 0 || coeff_modulus_size > context.key_modulus_size())
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            ctx_ = std::make_shared<SEALContext>(context);
+            n_ = context.poly_modulus_degree();
+            const std::size_t want = size * coeff_modulus_size * n_;
+            if (want > cap_)
+            {
+                std::uint64_t *nd = nullptr;
+                detail::check(cat_malloc(ctx_->handle(), want * sizeof(std::uint64_t), (void **)&nd));
+                if (d_)
+                {
+                    if (L_ == coeff_modulus_size && words())
+                    {
+                        std::vector<std::uint64_t> tmp(words());
+                        download(tmp.data());
+                        detail::check(cat_upload(ctx_->handle(), nd, tmp.data(), tmp.size() * 8, nullptr));
+                        detail::check(cat_stream_sync(ctx_->handle(), nullptr));
+                    }
+                    cat_free(ctx_->handle(), d_);
+                }
+                d_ = nd;
+                cap_ = want;
+            }
+            size_ = size;
+            L_ = coeff_modulus_size;
+        }
+        void resize(std::size_t size)
+        {
+            if (!ctx_)
+                throw std::logic_error("ciphertext is not bound to a context");
+            resize(*ctx_, L_, size);
+        }
+
+        // to_gpu() / to_cpu() (ciphertext.cuh:361-381)
+        void upload(const std::uint64_t *host)
+        {
+            detail::check(cat_upload(ctx_->handle(), d_, host, words() * 8, nullptr));
+            detail::check(cat_stream_sync(ctx_->handle(), nullptr));
+        }
+        void download(std::uint64_t *host) const
+        {
+            detail::check(cat_download(ctx_->handle(), host, d_, words() * 8, nullptr));
+            detail::check(cat_stream_sync(ctx_->handle(), nullptr));
+        }
+        std::vector<std::uint64_t> to_cpu() const
+        {
+            std::vector<std::uint64_t> out(words());
+            if (!out.empty())
+                download(out.data());
+            return out;
+        }
+
+        std::uint64_t *d_data() noexcept
+        {
+            return d_;
+        }
+        const std::uint64_t *d_data() const noexcept
+        {
+            return d_;
+        }
+        std::uint64_t *d_data(std::size_t poly_index) noexcept
+        {
+            return d_ + poly_index * L_ * n_;
+        }
+        std::size_t size() const noexcept
+        {
+            return size_;
+        }
+        std::size_t coeff_modulus_size() const noexcept
+        {
+            return L_;
+        }
+        std::size_t poly_modulus_degree() const noexcept
+        {
+            return n_;
+        }
+        bool is_ntt_form() const noexcept
+        {
+            return is_ntt_form_;
+        }
+        bool &is_ntt_form() noexcept
+        {
+            return is_ntt_form_;
+        }
+        double scale() const noexcept
+        {
+            return scale_;
+        }
+        double &scale() noexcept
+        {
+            return scale_;
+        }
+        std::size_t words() const noexcept
+        {
+            return size_ * L_ * n_;
+        }
+        const SEALContext *context() const noexcept
+        {
+            return ctx_.get();
+        }
+
+    private:
+        void reserve_words(std::size_t want)
+        {
+            if (want > cap_)
+            {
+                release_buffer();
+                detail::check(cat_malloc(ctx_->handle(), want * sizeof(std::uint64_t), (void **)&d_));
+                cap_ = want;
+            }
+        }
+        void release_buffer()
+        {
+            if (d_ && ctx_)
+                cat_free(ctx_->handle(), d_);
+            d_ = nullptr;
+            cap_ = 0;
+        }
+        void release()
+        {
+            release_buffer();
+            size_ = L_ = 0;
+        }
+
+        std::shared_ptr<SEALContext> ctx_;
+        std::uint64_t *d_ = nullptr;
+        std::size_t cap_ = 0, size_ = 0, L_ = 0, n_ = 0;
+        bool is_ntt_form_ = false;
+        double scale_ = 1.0;
+    };
+
+    // KSwitchKeys::data()[index] = vector<PublicKey>, one PublicKey per decomposition prime, each 2 x k x N
+    // words in NTT form (kswitchkeys.h:90-101).  Here every index holds one device array [k-1][2][k][N].
+    class KSwitchKeys
+    {
+    public:
+        explicit KSwitchKeys(const SEALContext &context) : ctx_(std::make_shared<SEALContext>(context))
+        {}
+        KSwitchKeys(const KSwitchKeys &) = delete;
+        KSwitchKeys &operator=(const KSwitchKeys &) = delete;
+        ~KSwitchKeys()
+        {
+            for (auto *p : keys_)
+                if (p)
+                    cat_free(ctx_->handle(), p);
+        }
+        std::size_t key_words() const noexcept
+        {
+            const std::size_t k = ctx_->key_modulus_size();
+            return (k - 1) * 2 * k * ctx_->poly_modulus_degree();
+        }
+        // host: [k-1][2][k][N] words as produced by KeyGenerator (keygenerator.cpp:301-334) on the CPU
+        void set_key(std::size_t index, const std::uint64_t *host)
+        {
+            if (!ctx_->using_keyswitching())
+                throw std::logic_error("keyswitching is not supported by the context");
+            if (keys_.size() <= index)
+                keys_.resize(index + 1, nullptr);
+            if (!keys_[index])
+                detail::check(cat_malloc(ctx_->handle(), key_words() * 8, (void **)&keys_[index]));
+            detail::check(cat_upload(ctx_->handle(), keys_[index], host, key_words() * 8, nullptr));
+            detail::check(cat_stream_sync(ctx_->handle(), nullptr));
+        }
+        bool has_index(std::size_t index) const noexcept
+        {
+            return index < keys_.size() && keys_[index];
+        }
+        const std::uint64_t *d_key(std::size_t index) const
+        {
+            if (!has_index(index))
+                throw std::invalid_argument("key not present");
+            return keys_[index];
+        }
+        std::size_t size() const noexcept
+        {
+            std::size_t c = 0;
+            for (auto *p : keys_)
+                c += p != nullptr;
+            return c;
+        }
+
+    protected:
+        std::shared_ptr<SEALContext> ctx_;
+        std::vector<std::uint64_t *> keys_;
+    };
+
+    class RelinKeys : public KSwitchKeys
+    {
+    public:
+        using KSwitchKeys::KSwitchKeys;
+        // relinkeys.h:58-64
+        static std::size_t get_index(std::size_t key_power)
+        {
+            if (key_power < 2)
+                throw std::invalid_argument("key_power cannot be less than 2");
+            return key_power - 2;
+        }
+        bool has_key(std::size_t key_power) const
+        {
+            return has_index(get_index(key_power));
+        }
+    };
+
+    class GaloisKeys : public KSwitchKeys
+    {
+    public:
+        using KSwitchKeys::KSwitchKeys;
+        // galoiskeys.h:48-50, util/galois.h:144-153
+        static std::size_t get_index(std::uint32_t galois_elt)
+        {
+            if (!(galois_elt & 1))
+                throw std::invalid_argument("galois_elt is not valid");
+            return (galois_elt - 1) >> 1;
+        }
+        bool has_key(std::uint32_t galois_elt) const
+        {
+            return has_index(get_index(galois_elt));
+        }
+    };
+
+    namespace util
+    {
+        // NTTTables of one prime of the context (util/ntt.h:69-199); the tables themselves are device-resident.
+        class NTTTables
+        {
+        public:
+            NTTTables(const SEALContext &context, std::uint32_t modulus_index)
+                : ctx_(context.handle()), index_(modulus_index)
+            {}
+            std::uint64_t get_root() const
+            {
+                return cat_ctx_root(ctx_, index_);
+            }
+            std::uint64_t modulus() const
+            {
+                return cat_ctx_modulus(ctx_, index_);
+            }
+            cat_ctx *ctx() const noexcept
+            {
+                return ctx_;
+            }
+            std::uint32_t index() const noexcept
+            {
+                return index_;
+            }
+
+        private:
+            cat_ctx *ctx_;
+            std::uint32_t index_;
+        };
+        using Modulus = NTTTables; // the coefficient-wise ops only need "which prime"
+
+        // CoeffIter overloads (util/ntt.h:201-270): operand = N device words
+        inline void ntt_negacyclic_harvey_lazy(std::uint64_t *d_operand, const NTTTables &t)
+        {
+            const std::uint32_t id = t.index();
+            detail::check(cat_ntt_forward(t.ctx(), d_operand, &id, 1, 1, 1, nullptr));
+        }
+        inline void ntt_negacyclic_harvey(std::uint64_t *d_operand, const NTTTables &t)
+        {
+            const std::uint32_t id = t.index();
+            detail::check(cat_ntt_forward(t.ctx(), d_operand, &id, 1, 1, 0, nullptr));
+        }
+        inline void inverse_ntt_negacyclic_harvey_lazy(std::uint64_t *d_operand, const NTTTables &t)
+        {
+            const std::uint32_t id = t.index();
+            detail::check(cat_ntt_inverse(t.ctx(), d_operand, &id, 1, 1, 1, nullptr));
+        }
+        inline void inverse_ntt_negacyclic_harvey(std::uint64_t *d_operand, const NTTTables &t)
+        {
+            const std::uint32_t id = t.index();
+            detail::check(cat_ntt_inverse(t.ctx(), d_operand, &id, 1, 1, 0, nullptr));
+        }
+        // (operand1, operand2, coeff_count, modulus, result), polyarithsmallmod.cuh:172-175, 544-546;
+        // coeff_count must be the context's N (one limb per call, like the CoeffIter overloads)
+        inline void add_poly_coeffmod(const std::uint64_t *a, const std::uint64_t *b, std::size_t, const Modulus &m,
+                                      std::uint64_t *r)
+        {
+            const std::uint32_t id = m.index();
+            detail::check(cat_add(m.ctx(), a, b, r, &id, 1, 1, nullptr));
+        }
+        inline void sub_poly_coeffmod(const std::uint64_t *a, const std::uint64_t *b, std::size_t, const Modulus &m,
+                                      std::uint64_t *r)
+        {
+            const std::uint32_t id = m.index();
+            detail::check(cat_sub(m.ctx(), a, b, r, &id, 1, 1, nullptr));
+        }
+        inline void negate_poly_coeffmod(const std::uint64_t *a, std::size_t, const Modulus &m, std::uint64_t *r)
+        {
+            const std::uint32_t id = m.index();
+            detail::check(cat_negate(m.ctx(), a, r, &id, 1, 1, nullptr));
+        }
+        inline void dyadic_product_coeffmod(const std::uint64_t *a, const std::uint64_t *b, std::size_t,
+                                            const Modulus &m, std::uint64_t *r)
+        {
+            const std::uint32_t id = m.index();
+            detail::check(cat_dyadic(m.ctx(), a, b, r, &id, 1, 1, nullptr));
+        }
+    } // namespace util
+
+    class Evaluator
+    {
+    public:
+        explicit Evaluator(const SEALContext &context) : context_(context)
+        {}
+
+        void negate_inplace(Ciphertext &encrypted) const
+        {
+            verify(encrypted, "encrypted");
+            detail::check(cat_negate(h(), encrypted.d_data(), encrypted.d_data(), nullptr,
+                                     (std::uint32_t)encrypted.coeff_modulus_size(), (std::uint32_t)encrypted.size(),
+                                     nullptr));
+        }
+
+        // evaluator.cpp:133-215 for equal sizes (the larger-operand copy branch is host bookkeeping)
+        void add_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
+        {
+            check_pair(encrypted1, encrypted2);
+            if (encrypted1.size() != encrypted2.size())
+                throw std::logic_error("unsupported: operands of different size");
+            detail::check(cat_add(h(), encrypted1.d_data(), encrypted2.d_data(), encrypted1.d_data(), nullptr,
+                                  (std::uint32_t)encrypted1.coeff_modulus_size(), (std::uint32_t)encrypted1.size(),
+                                  nullptr));
+        }
+
+        void sub_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
+        {
+            check_pair(encrypted1, encrypted2);
+            if (encrypted1.size() != encrypted2.size())
+                throw std::logic_error("unsupported: operands of different size");
+            detail::check(cat_sub(h(), encrypted1.d_data(), encrypted2.d_data(), encrypted1.d_data(), nullptr,
+                                  (std::uint32_t)encrypted1.coeff_modulus_size(), (std::uint32_t)encrypted1.size(),
+                                  nullptr));
+        }
+
+        // evaluator.cpp:352-393 -> ckks_multiply :569-708 / bfv_multiply :395-567 (sizes 2 x 2 -> 3)
+        void multiply_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
+        {
+            verify(encrypted1, "encrypted1");
+            verify(encrypted2, "encrypted2");
+            if (encrypted1.coeff_modulus_size() != encrypted2.coeff_modulus_size())
+                throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+            if (encrypted1.size() != 2 || encrypted2.size() != 2)
+                throw std::logic_error("unsupported: only size-2 operands are multiplied on the device");
+            const std::uint32_t L = (std::uint32_t)encrypted1.coeff_modulus_size();
+            Ciphertext dest(context_, L, 3);
+            switch (context_.parms().scheme())
+            {
+            case scheme_type::ckks:
+                if (!encrypted1.is_ntt_form() || !encrypted2.is_ntt_form())
+                    throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
+                detail::check(cat_ckks_multiply(h(), encrypted1.d_data(), encrypted2.d_data(), dest.d_data(), L, 1, nullptr));
+                dest.is_ntt_form() = true;
+                dest.scale() = encrypted1.scale() * encrypted2.scale();
+                break;
+            case scheme_type::bfv:
+                if (encrypted1.is_ntt_form() || encrypted2.is_ntt_form())
+                    throw std::invalid_argument("encrypted1 or encrypted2 cannot be in NTT form");
+                detail::check(cat_bfv_multiply(h(), encrypted1.d_data(), encrypted2.d_data(), dest.d_data(), L, 1, nullptr));
+                dest.scale() = encrypted1.scale();
+                break;
+            default:
+                throw std::invalid_argument("unsupported scheme");
+            }
+            encrypted1 = std::move(dest);
+        }
+        void multiply(const Ciphertext &encrypted1, const Ciphertext &encrypted2, Ciphertext &destination) const
+        {
+            if (&encrypted2 == &destination)
+            {
+                Ciphertext tmp(encrypted1);
+                multiply_inplace(tmp, encrypted2);
+                destination = std::move(tmp);
+                return;
+            }
+            destination = encrypted1;
+            multiply_inplace(destination, encrypted2);
+        }
+
+        // evaluator.cpp:1144-1199 (destination_size 2): one key switch per dropped polynomial
+        void relinearize_inplace(Ciphertext &encrypted, const RelinKeys &relin_keys) const
+        {
+            verify(encrypted, "encrypted");
+            std::size_t size = encrypted.size();
+            if (size < 2)
+                throw std::invalid_argument("destination_size must be at least 2 and less than or equal to current count");
+            if (relin_keys.size() < size - 2)
+                throw std::invalid_argument("not enough relinearization keys");
+            const std::uint32_t L = (std::uint32_t)encrypted.coeff_modulus_size();
+            while (size > 2)
+            {
+                const std::uint64_t *key = relin_keys.d_key(RelinKeys::get_index(size - 1));
+                detail::check(cat_switch_key(h(), encrypted.d_data(), encrypted.d_data(size - 1), key, L, 1, nullptr));
+                --size;
+            }
+            encrypted.resize(2);
+        }
+
+        // evaluator.cpp:1481-1519
+        void rescale_to_next(const Ciphertext &encrypted, Ciphertext &destination) const
+        {
+            verify(encrypted, "encrypted");
+            if (encrypted.coeff_modulus_size() < 2)
+                throw std::invalid_argument("end of modulus switching chain reached");
+            if (context_.parms().scheme() != scheme_type::ckks)
+                throw std::invalid_argument("unsupported operation for scheme type");
+            if (!encrypted.is_ntt_form())
+                throw std::invalid_argument("CKKS encrypted must be in NTT form");
+            scale_to_next(encrypted, destination);
+        }
+        void rescale_to_next_inplace(Ciphertext &encrypted) const
+        {
+            Ciphertext dest;
+            rescale_to_next(encrypted, dest);
+            encrypted = std::move(dest);
+        }
+
+        // evaluator.cpp:1347-1389: BFV -> mod_switch_scale_to_next, CKKS -> mod_switch_drop_to_next
+        void mod_switch_to_next_inplace(Ciphertext &encrypted) const
+        {
+            verify(encrypted, "encrypted");
+            if (encrypted.coeff_modulus_size() < 2)
+                throw std::invalid_argument("end of modulus switching chain reached");
+            Ciphertext dest;
+            if (context_.parms().scheme() == scheme_type::bfv)
+            {
+                if (encrypted.is_ntt_form())
+                    throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+                scale_to_next(encrypted, dest);
+                dest.scale() = encrypted.scale();
+            }
+            else if (context_.parms().scheme() == scheme_type::ckks)
+            {
+                if (!encrypted.is_ntt_form())
+                    throw std::invalid_argument("CKKS encrypted must be in NTT form");
+                const std::uint32_t L = (std::uint32_t)encrypted.coeff_modulus_size();
+                dest.resize(context_, L - 1, encrypted.size());
+                detail::check(cat_mod_drop(h(), encrypted.d_data(), dest.d_data(), L, (std::uint32_t)encrypted.size(), 1, nullptr));
+                dest.is_ntt_form() = true;
+                dest.scale() = encrypted.scale();
+            }
+            else
+                throw std::invalid_argument("unsupported scheme");
+            encrypted = std::move(dest);
+        }
+
+        // evaluator.cpp:2267-2360
+        void transform_to_ntt_inplace(Ciphertext &encrypted) const
+        {
+            verify(encrypted, "encrypted");
+            if (encrypted.is_ntt_form())
+                throw std::invalid_argument("encrypted is already in NTT form");
+            detail::check(cat_ntt_forward(h(), encrypted.d_data(), nullptr, (std::uint32_t)encrypted.coeff_modulus_size(),
+                                          (std::uint32_t)encrypted.size(), 0, nullptr));
+            encrypted.is_ntt_form() = true;
+        }
+        void transform_from_ntt_inplace(Ciphertext &encrypted_ntt) const
+        {
+            verify(encrypted_ntt, "encrypted_ntt");
+            if (!encrypted_ntt.is_ntt_form())
+                throw std::invalid_argument("encrypted_ntt is not in NTT form");
+            detail::check(cat_ntt_inverse(h(), encrypted_ntt.d_data(), nullptr,
+                                          (std::uint32_t)encrypted_ntt.coeff_modulus_size(),
+                                          (std::uint32_t)encrypted_ntt.size(), 0, nullptr));
+            encrypted_ntt.is_ntt_form() = false;
+        }
+
+        // evaluator.cpp:2362-2464
+        void apply_galois_inplace(Ciphertext &encrypted, std::uint32_t galois_elt, const GaloisKeys &galois_keys) const
+        {
+            verify(encrypted, "encrypted");
+            if (!(galois_elt & 1) || galois_elt >= 2 * (std::uint64_t)context_.poly_modulus_degree())
+                throw std::invalid_argument("Galois element is not valid");
+            if (!galois_keys.has_key(galois_elt))
+                throw std::invalid_argument("Galois key not present");
+            if (encrypted.size() > 2)
+                throw std::invalid_argument("encrypted size must be 2");
+            detail::check(cat_apply_galois_inplace(h(), encrypted.d_data(), galois_elt,
+                                                   galois_keys.d_key(GaloisKeys::get_index(galois_elt)),
+                                                   (std::uint32_t)encrypted.coeff_modulus_size(), 1, nullptr));
+        }
+
+        // evaluator.h:1195-1237 -> rotate_internal (evaluator.cpp:2466-2521), incl. the NAF fallback
+        void rotate_vector_inplace(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys) const
+        {
+            if (context_.parms().scheme() != scheme_type::ckks)
+                throw std::logic_error("unsupported scheme");
+            rotate_internal(encrypted, steps, galois_keys);
+        }
+        void rotate_rows_inplace(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys) const
+        {
+            if (context_.parms().scheme() != scheme_type::bfv)
+                throw std::logic_error("unsupported scheme");
+            rotate_internal(encrypted, steps, galois_keys);
+        }
+        void complex_conjugate_inplace(Ciphertext &encrypted, const GaloisKeys &galois_keys) const
+        {
+            if (context_.parms().scheme() != scheme_type::ckks)
+                throw std::logic_error("unsupported scheme");
+            apply_galois_inplace(encrypted, cat_galois_elt_from_step(log_n(), 0), galois_keys);
+        }
+
+    private:
+        cat_ctx *h() const noexcept
+        {
+            return context_.handle();
+        }
+        std::uint32_t log_n() const noexcept
+        {
+            return cat_ctx_log_n(h());
+        }
+        void verify(const Ciphertext &c, const char *name) const
+        {
+            if (!c.d_data() || c.size() < 2 || c.poly_modulus_degree() != context_.poly_modulus_degree() ||
+                c.coeff_modulus_size() == 0 || c.coeff_modulus_size() > context_.key_modulus_size() ||
+                (c.context() && c.context()->handle() != h()))
+                throw std::invalid_argument(std::string(name) + " is not valid for encryption parameters");
+        }
+        void check_pair(const Ciphertext &a, const Ciphertext &b) const
+        {
+            verify(a, "encrypted1");
+            verify(b, "encrypted2");
+            if (a.coeff_modulus_size() != b.coeff_modulus_size())
+                throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+            if (a.is_ntt_form() != b.is_ntt_form())
+                throw std::invalid_argument("NTT form mismatch");
+            if (a.scale() != b.scale())
+                throw std::invalid_argument("scale mismatch");
+        }
+        // mod_switch_scale_to_next (evaluator.cpp:1201-1280)
+        void scale_to_next(const Ciphertext &encrypted, Ciphertext &destination) const
+        {
+            const std::uint32_t L = (std::uint32_t)encrypted.coeff_modulus_size();
+            Ciphertext dest(context_, L - 1, encrypted.size());
+            detail::check(cat_rescale(h(), encrypted.d_data(), dest.d_data(), L, (std::uint32_t)encrypted.size(), 1, nullptr));
+            dest.is_ntt_form() = encrypted.is_ntt_form();
+            if (context_.parms().scheme() == scheme_type::ckks)
+                dest.scale() = encrypted.scale() / (double)cat_ctx_modulus(h(), L - 1);
+            destination = std::move(dest);
+        }
+        void rotate_internal(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys) const
+        {
+            if (!context_.using_keyswitching())
+                throw std::logic_error("encryption parameters do not support batching");
+            if (steps == 0)
+                return;
+            const std::size_t slots = context_.poly_modulus_degree() >> 1;
+            const std::uint32_t elt = cat_galois_elt_from_step(log_n(), steps);
+            if (elt == 0)
+                throw std::invalid_argument("step count too large");
+            if (galois_keys.has_key(elt))
+            {
+                apply_galois_inplace(encrypted, elt, galois_keys);
+                return;
+            }
+            // NAF of steps; every term must have its power-of-two key (evaluator.cpp:2501-2519)
+            std::vector<int> naf;
+            {
+                long long v = steps;
+                int bit = 0;
+                const bool neg = v < 0;
+                if (neg)
+                    v = -v;
+                while (v)
+                {
+                    int z = 0;
+                    if (v & 1)
+                    {
+                        z = 2 - (int)(v & 3);
+                        v -= z;
+                    }
+                    if (z)
+                        naf.push_back((neg ? -z : z) * (1 << bit));
+                    v >>= 1;
+                    ++bit;
+                }
+            }
+            if (naf.size() == 1)
+                throw std::invalid_argument("Galois key not present");
+            for (int step : naf)
+                if ((std::size_t)std::abs(step) != slots)
+                    rotate_internal(encrypted, step, galois_keys);
+        }
+
+        SEALContext context_;
+    };
+} // namespace seal

@@ -1,0 +1,264 @@
+// Parity test of the C++ facade (cat_amd/host/seal_hip.hpp) written the way the reference's own tests drive
+// seal::Evaluator (native/tests/seal/evaluator.cpp:3354-3623: multiply, relinearize, rescale, rotate), but
+// bit-exact against the CPU oracle instead of decrypt-and-compare with a tolerance.  Needs a GPU; built by
+// `make facade_test`, run by tests/test_gpu_facade.py.  Test infrastructure: links oracle/libseal_oracle.so.
+#include "../../cat_amd/host/seal_hip.hpp"
+#include "../../oracle/seal_oracle.h"
+
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+using namespace seal;
+typedef std::vector<uint64_t> vec;
+
+static int failures = 0;
+#define EXPECT(cond)                                                          \
+    do                                                                        \
+    {                                                                         \
+        if (!(cond))                                                          \
+        {                                                                     \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);       \
+            ++failures;                                                       \
+        }                                                                     \
+    } while (0)
+
+template <typename E>
+static bool throws(const std::function<void()> &f)
+{
+    try
+    {
+        f();
+    }
+    catch (const E &)
+    {
+        return true;
+    }
+    catch (...)
+    {
+        return false;
+    }
+    return false;
+}
+
+static vec uniform(so_context *oc, size_t L, size_t polys, size_t n, uint64_t seed)
+{
+    vec v(polys * L * n);
+    so_fill_uniform(oc, L, polys, seed, v.data());
+    return v;
+}
+
+static void test_util_ntt_known_answers()
+{
+    // native/tests/seal/util/ntt.cpp:77-101
+    EncryptionParameters parms(scheme_type::none);
+    parms.set_poly_modulus_degree(2);
+    parms.set_coeff_modulus({ 0xffffffffffc0001ULL });
+    SEALContext context(parms);
+    util::NTTTables tables(context, 0);
+    Ciphertext buf(context, 1, 2); // 2 polys x 1 limb x 2 words of device memory
+    const uint64_t cases[3][4] = { { 0, 0, 0, 0 }, { 1, 0, 1, 1 }, { 1, 1, 288794978602139553ULL, 864126526004445282ULL } };
+    for (auto &c : cases)
+    {
+        vec h = { c[0], c[1], 0, 0 };
+        buf.upload(h.data());
+        util::ntt_negacyclic_harvey(buf.d_data(), tables);
+        h = buf.to_cpu();
+        EXPECT(h[0] == c[2] && h[1] == c[3]);
+        util::inverse_ntt_negacyclic_harvey(buf.d_data(), tables);
+        h = buf.to_cpu();
+        EXPECT(h[0] == c[0] && h[1] == c[1]);
+    }
+}
+
+static void test_ckks()
+{
+    const int log_n = 12;
+    const size_t n = 4096;
+    const int bits[4] = { 50, 40, 40, 50 };
+    vec primes(4);
+    EXPECT(so_coeff_modulus_create(n, bits, 4, primes.data()) == 0);
+    const size_t k = 4, L = 3;
+    so_context *oc = so_context_create(log_n, primes.data(), k, SO_SCHEME_CKKS, 0);
+
+    EncryptionParameters parms(scheme_type::ckks);
+    parms.set_poly_modulus_degree(n);
+    parms.set_coeff_modulus(primes);
+    SEALContext context(parms);
+    Evaluator evaluator(context);
+    EXPECT(context.first_level_size() == L);
+
+    vec sk(k * n), rk((k - 1) * 2 * k * n), gk1(rk.size()), gk2(rk.size()), gkc(rk.size());
+    so_sample_ternary_ntt(oc, 1, sk.data());
+    so_gen_relin_key(oc, sk.data(), 2, rk.data());
+    const uint32_t elt1 = so_galois_elt_from_step(log_n, 1), elt2 = so_galois_elt_from_step(log_n, 2),
+                   eltc = so_galois_elt_from_step(log_n, 0);
+    so_gen_galois_key(oc, sk.data(), elt1, 3, gk1.data());
+    so_gen_galois_key(oc, sk.data(), elt2, 4, gk2.data());
+    so_gen_galois_key(oc, sk.data(), eltc, 5, gkc.data());
+    RelinKeys relin_keys(context);
+    relin_keys.set_key(RelinKeys::get_index(2), rk.data());
+    GaloisKeys galois_keys(context);
+    galois_keys.set_key(GaloisKeys::get_index(elt1), gk1.data());
+    galois_keys.set_key(GaloisKeys::get_index(elt2), gk2.data());
+    galois_keys.set_key(GaloisKeys::get_index(eltc), gkc.data());
+    EXPECT(relin_keys.has_key(2) && galois_keys.has_key(elt1) && !galois_keys.has_key(5));
+
+    vec x = uniform(oc, L, 2, n, 10), y = uniform(oc, L, 2, n, 11);
+    Ciphertext encrypted1(context, L), encrypted2(context, L);
+    encrypted1.upload(x.data());
+    encrypted2.upload(y.data());
+    const double delta = std::pow(2.0, 40);
+    encrypted1.scale() = encrypted2.scale() = delta;
+
+    // multiply needs NTT form (evaluator.cpp:571)
+    EXPECT(throws<std::invalid_argument>([&] { evaluator.multiply_inplace(encrypted1, encrypted2); }));
+    encrypted1.is_ntt_form() = encrypted2.is_ntt_form() = true;
+
+    // add / sub / negate (evaluator.cpp:88-351)
+    {
+        Ciphertext s(encrypted1);
+        evaluator.add_inplace(s, encrypted2);
+        vec got = s.to_cpu(), exp(x.size());
+        for (size_t p = 0; p < 2; ++p)
+            for (size_t j = 0; j < L; ++j)
+                so_add_poly_coeffmod(&x[(p * L + j) * n], &y[(p * L + j) * n], n, &so_context_tables(oc, j)->mod,
+                                     &exp[(p * L + j) * n]);
+        EXPECT(got == exp);
+        evaluator.sub_inplace(s, encrypted2);
+        EXPECT(s.to_cpu() == x);
+        evaluator.negate_inplace(s);
+        evaluator.negate_inplace(s);
+        EXPECT(s.to_cpu() == x);
+    }
+
+    // multiply -> relinearize -> rescale (tests/evaluator.cpp:3539-3623)
+    vec exp3(3 * L * n, 0);
+    std::memcpy(exp3.data(), x.data(), x.size() * 8);
+    so_ckks_multiply(oc, L, exp3.data(), y.data());
+    evaluator.multiply_inplace(encrypted1, encrypted2);
+    EXPECT(encrypted1.size() == 3 && encrypted1.is_ntt_form() && encrypted1.scale() == delta * delta);
+    EXPECT(encrypted1.to_cpu() == exp3);
+
+    so_relinearize(oc, L, exp3.data(), rk.data());
+    evaluator.relinearize_inplace(encrypted1, relin_keys);
+    EXPECT(encrypted1.size() == 2);
+    vec exp2(exp3.begin(), exp3.begin() + 2 * L * n);
+    EXPECT(encrypted1.to_cpu() == exp2);
+
+    vec expr(2 * (L - 1) * n);
+    so_mod_switch_scale_to_next(oc, L, exp2.data(), 2, expr.data());
+    Ciphertext rescaled;
+    evaluator.rescale_to_next(encrypted1, rescaled);
+    EXPECT(rescaled.coeff_modulus_size() == L - 1 && rescaled.to_cpu() == expr);
+    EXPECT(rescaled.scale() == delta * delta / (double)primes[L - 1]);
+
+    // rotate_vector / complex_conjugate (tests/evaluator.cpp:4147, disabled in the reference build)
+    {
+        Ciphertext r(encrypted2);
+        vec e = y;
+        so_apply_galois_inplace(oc, L, e.data(), elt1, gk1.data());
+        evaluator.rotate_vector_inplace(r, 1, galois_keys);
+        EXPECT(r.to_cpu() == e);
+        // step 3 has no key: NAF 3 = 4 - 1 needs the key of step 4 -> "Galois key not present"
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.rotate_vector_inplace(r, 3, galois_keys); }));
+        vec e2 = e;
+        so_apply_galois_inplace(oc, L, e2.data(), eltc, gkc.data());
+        evaluator.complex_conjugate_inplace(r, galois_keys);
+        EXPECT(r.to_cpu() == e2);
+        EXPECT(throws<std::logic_error>([&] { evaluator.rotate_rows_inplace(r, 1, galois_keys); }));
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.apply_galois_inplace(r, 4, galois_keys); }));
+    }
+
+    // mod_switch_to_next (drop) and the NTT transforms
+    {
+        Ciphertext m(encrypted2);
+        vec e(2 * (L - 1) * n);
+        so_mod_switch_drop_to_next(oc, L, y.data(), 2, e.data());
+        evaluator.mod_switch_to_next_inplace(m);
+        EXPECT(m.coeff_modulus_size() == L - 1 && m.to_cpu() == e);
+        Ciphertext t(encrypted2);
+        vec f = y;
+        so_transform_from_ntt(oc, L, f.data(), 2);
+        evaluator.transform_from_ntt_inplace(t);
+        EXPECT(!t.is_ntt_form() && t.to_cpu() == f);
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.transform_from_ntt_inplace(t); }));
+        evaluator.transform_to_ntt_inplace(t);
+        EXPECT(t.to_cpu() == y);
+        // chain end (evaluator.cpp:1488-1491)
+        evaluator.mod_switch_to_next_inplace(m);
+        EXPECT(m.coeff_modulus_size() == 1);
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.rescale_to_next_inplace(m); }));
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.mod_switch_to_next_inplace(m); }));
+    }
+    so_context_destroy(oc);
+}
+
+static void test_bfv()
+{
+    const int log_n = 12;
+    const size_t n = 4096;
+    const int bits[3] = { 36, 36, 37 };
+    const uint64_t t = 65537;
+    vec primes(3);
+    EXPECT(so_coeff_modulus_create(n, bits, 3, primes.data()) == 0);
+    const size_t k = 3, L = 2;
+    so_context *oc = so_context_create(log_n, primes.data(), k, SO_SCHEME_BFV, t);
+
+    EncryptionParameters parms(scheme_type::bfv);
+    parms.set_poly_modulus_degree(n);
+    parms.set_coeff_modulus(primes);
+    parms.set_plain_modulus(t);
+    SEALContext context(parms);
+    Evaluator evaluator(context);
+
+    vec sk(k * n), rk((k - 1) * 2 * k * n);
+    so_sample_ternary_ntt(oc, 1, sk.data());
+    so_gen_relin_key(oc, sk.data(), 2, rk.data());
+    RelinKeys relin_keys(context);
+    relin_keys.set_key(0, rk.data());
+
+    vec x = uniform(oc, L, 2, n, 20), y = uniform(oc, L, 2, n, 21);
+    Ciphertext encrypted1(context, L), encrypted2(context, L);
+    encrypted1.upload(x.data());
+    encrypted2.upload(y.data());
+    vec exp3(3 * L * n, 0);
+    std::memcpy(exp3.data(), x.data(), x.size() * 8);
+    so_bfv_multiply(oc, L, exp3.data(), y.data());
+    evaluator.multiply_inplace(encrypted1, encrypted2);
+    EXPECT(encrypted1.size() == 3 && encrypted1.to_cpu() == exp3);
+    so_relinearize(oc, L, exp3.data(), rk.data());
+    evaluator.relinearize_inplace(encrypted1, relin_keys);
+    vec exp2(exp3.begin(), exp3.begin() + 2 * L * n);
+    EXPECT(encrypted1.to_cpu() == exp2);
+    // BFV mod switch = divide_and_round_q_last_inplace (util/rns.cpp:789-828)
+    vec e(2 * (L - 1) * n);
+    so_mod_switch_scale_to_next(oc, L, exp2.data(), 2, e.data());
+    evaluator.mod_switch_to_next_inplace(encrypted1);
+    EXPECT(encrypted1.to_cpu() == e);
+    EXPECT(throws<std::invalid_argument>([&] { evaluator.rescale_to_next_inplace(encrypted2); }));
+    so_context_destroy(oc);
+}
+
+int main()
+{
+    try
+    {
+        test_util_ntt_known_answers();
+        test_ckks();
+        test_bfv();
+    }
+    catch (const std::exception &e)
+    {
+        std::printf("FAIL: unexpected exception: %s\n", e.what());
+        return 2;
+    }
+    if (failures)
+    {
+        std::printf("%d facade check(s) failed\n", failures);
+        return 1;
+    }
+    std::printf("facade ok: seal::Evaluator / seal::util over libcat_amd.so match the CPU oracle bit for bit\n");
+    return 0;
+}
