@@ -166,6 +166,15 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
         ctx->n_mod = (uint32_t)all.size();
         std::vector<DevMod> dm(ctx->n_mod);
         std::vector<MulOp> fwd(ctx->n_mod * n), inv(ctx->n_mod * n);
+        // split-Shoup tables, structure of arrays per prime: [w0 | w1 | q0,q1]; the inverse one is stored shifted by
+        // one entry (entry j = inv_root_powers[j + 1], ntt.hip Fast::table)
+        std::vector<u64> fwd3(ctx->n_mod * 3 * n, 0), inv3(ctx->n_mod * 3 * n, 0);
+        std::vector<NttMod> nm(ctx->n_mod);
+        auto split3 = [](const HostMod &m, u64 w) {
+            u64 t[3];
+            m.split(w, t);
+            return MulOp3{ t[0], t[1], (u32)t[2], (u32)(t[2] >> 32) };
+        };
         for (uint32_t i = 0; i < ctx->n_mod; ++i)
         {
             HostMod hm(all[i]);
@@ -182,6 +191,25 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
             dm[i].pad = 0;
             std::memcpy(&fwd[i * n], t.fwd.data(), n * sizeof(MulOp));
             std::memcpy(&inv[i * n], t.inv.data(), n * sizeof(MulOp));
+            for (size_t j = 0; j < n; ++j)
+            {
+                u64 c[3];
+                hm.split(t.fwd[2 * j], c);
+                for (int e = 0; e < 3; ++e)
+                    fwd3[(i * 3 + e) * n + j] = c[e];
+                if (j + 1 < n)
+                {
+                    hm.split(t.inv[2 * (j + 1)], c);
+                    for (int e = 0; e < 3; ++e)
+                        inv3[(i * 3 + e) * n + j] = c[e];
+                }
+            }
+            nm[i].q = hm.q;
+            nm[i].pad = 0;
+            nm[i].inv_n = MulOp{ t.inv_n, hm.shoup(t.inv_n) };
+            nm[i].inv_n_w = MulOp{ t.inv_n_w, hm.shoup(t.inv_n_w) };
+            nm[i].inv_n3 = split3(hm, t.inv_n);
+            nm[i].inv_n_w3 = split3(hm, t.inv_n_w);
         }
         const uint32_t k = ctx->k;
         ctx->h_inv_mod.assign((size_t)k * k, MulOp{ 0, 0 });
@@ -203,6 +231,12 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
             st = upload_vec(&ctx->d_tw_fwd, fwd);
         if (st == CAT_OK)
             st = upload_vec(&ctx->d_tw_inv, inv);
+        if (st == CAT_OK)
+            st = upload_vec(&ctx->d_tw3_fwd, fwd3);
+        if (st == CAT_OK)
+            st = upload_vec(&ctx->d_tw3_inv, inv3);
+        if (st == CAT_OK)
+            st = upload_vec(&ctx->d_nttmods, nm);
         if (st == CAT_OK)
             st = upload_vec(&ctx->d_inv_mod, ctx->h_inv_mod);
         if (st == CAT_OK)
@@ -244,6 +278,9 @@ cat_status cat_ctx_destroy(cat_ctx *ctx)
     if (ctx->d_mods) (void)hipFree(ctx->d_mods);
     if (ctx->d_tw_fwd) (void)hipFree(ctx->d_tw_fwd);
     if (ctx->d_tw_inv) (void)hipFree(ctx->d_tw_inv);
+    if (ctx->d_tw3_fwd) (void)hipFree(ctx->d_tw3_fwd);
+    if (ctx->d_tw3_inv) (void)hipFree(ctx->d_tw3_inv);
+    if (ctx->d_nttmods) (void)hipFree(ctx->d_nttmods);
     if (ctx->d_inv_mod) (void)hipFree(ctx->d_inv_mod);
     if (ctx->d_half_mod) (void)hipFree(ctx->d_half_mod);
     if (ctx->ws) (void)hipFree(ctx->ws);
@@ -348,7 +385,8 @@ static cat_status ntt_common(cat_ctx *ctx, bool fwd, uint64_t *d_data, const uin
     st = make_map(ctx, limb_ids, n_limbs, map);
     if (st != CAT_OK)
         return st;
-    return launch_ntt(ctx, fwd, (u64 *)d_data, map, n_limbs, n_polys, lazy != 0, (hipStream_t)s);
+    // lazy results are promised to be the reference's exact representatives -> exact arithmetic
+    return launch_ntt(ctx, fwd, (u64 *)d_data, map, n_limbs, n_polys, lazy != 0, (hipStream_t)s, lazy != 0);
 }
 
 cat_status cat_ntt_forward(cat_ctx *ctx, uint64_t *d_data, const uint32_t *limb_ids, uint32_t n_limbs,

@@ -54,6 +54,9 @@ struct cat_ctx
     DevMod *d_mods = nullptr;
     MulOp *d_tw_fwd = nullptr; // [n_mod][n]
     MulOp *d_tw_inv = nullptr; // [n_mod][n]
+    cat::u64 *d_tw3_fwd = nullptr; // [n_mod][3][n] split-Shoup form of the same twiddles (fast path): w0 | w1 | q0,q1
+    cat::u64 *d_tw3_inv = nullptr; // [n_mod][3][n], shifted by one entry
+    NttMod *d_nttmods = nullptr; // [n_mod]
     MulOp *d_inv_mod = nullptr; // [k][k]: entry [a][b] = q_a^-1 mod q_b
     std::vector<MulOp> h_inv_mod;
     cat::u64 *d_half_mod = nullptr; // [k][k]: entry [a][b] = (q_a >> 1) mod q_b
@@ -83,13 +86,15 @@ namespace cat
     cat_status make_map(const cat_ctx *ctx, const uint32_t *limb_ids, uint32_t n_limbs, LimbMap &out);
 
     // ---- kernel launchers (ntt.hip, polyops.hip, keyswitch.hip, bfv.hip) ----
+    // exact = true reproduces SEAL's lazy representatives bit for bit (the C ABI's lazy calls); internal callers
+    // and fully reduced transforms use the faster split-Shoup arithmetic (same values modulo q, same ranges).
     cat_status launch_ntt(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
-                          uint32_t n_polys, bool lazy, hipStream_t s);
+                          uint32_t n_polys, bool lazy, hipStream_t s, bool exact = false);
     // general form: objects `poly_stride` words apart; limb j uses modulus map.id[j / limb_group];
     // skip_diag skips limbs with j % limb_group == j / limb_group (key switching's I == J operands)
     cat_status launch_ntt_ex(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
                              uint32_t n_polys, bool lazy, u64 poly_stride, uint32_t limb_group, bool skip_diag,
-                             hipStream_t s);
+                             hipStream_t s, bool exact = false);
     cat_status launch_ew(cat_ctx *ctx, int op, const u64 *a, const u64 *b, u64 *out, const LimbMap &map,
                          uint32_t n_limbs, uint32_t n_polys, hipStream_t s);
     cat_status launch_scalar(cat_ctx *ctx, int op, const u64 *a, const u64 *scalars, u64 *out, const LimbMap &map,

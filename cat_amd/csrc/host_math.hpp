@@ -54,6 +54,14 @@ namespace cat
         {
             return u64((u128(w) << 64) / q);
         }
+        // split-Shoup constants of w < q (modarith.cuh): out = {W0, W1, Q0 | Q1 << 32}
+        void split(u64 w, u64 out[3]) const
+        {
+            const u64 w1 = u64((u128(w) << 32) % q);
+            out[0] = w;
+            out[1] = w1;
+            out[2] = u64((u128(w) << 32) / q) | (u64((u128(w1) << 32) / q) << 32);
+        }
     };
 
     inline bool invert_mod(u64 a, u64 m, u64 &out)

@@ -109,6 +109,60 @@ __device__ __forceinline__ void mac128(u64 &lo, u64 &hi, u64 a, u64 b)
     hi += ph + (lo < pl);
 }
 
+// ---- "split Shoup" multiply (internal fast path; representatives differ from SEAL's lazy ones) ------------
+// For a constant w < q:  W0 = w, W1 = w * 2^32 mod q, Q0 = floor(W0 * 2^32 / q), Q1 = floor(W1 * 2^32 / q).
+// With x = x1 * 2^32 + x0:  x * w = x0 * W0 + x1 * W1 (mod q) and each 32-bit Shoup step loses less than 2q, so
+//   r = x0*W0 + x1*W1 - (mulhi32(x0,Q0) + mulhi32(x1,Q1)) * q   lies in [0, 4q)   for ANY 64-bit x.
+// 10 32-bit multiplies like the 64-bit Shoup product, but no 64x64 high product: two v_mad_u64_u32 chains with
+// natural register pairs (no carry handling, no pair building), which is what the VALU-bound NTT needs
+// (tools/ubench_bfly.hip: 1.37 -> 1.59 T butterflies/s on MI355X).
+struct __attribute__((aligned(8))) MulOp3
+{
+    u64 w0;
+    u64 w1;
+    u32 q0;
+    u32 q1;
+};
+
+// nq = 2^64 - q
+__device__ __forceinline__ u64 mul_split(u64 x, u64 W0, u64 W1, u32 Q0, u32 Q1, u64 nq)
+{
+    u64 E, M;
+    u32 h0, h1;
+    asm("v_mul_hi_u32 %2, %4, %10\n\t"
+        "v_mul_hi_u32 %3, %5, %11\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %6, 0\n\t"
+        "v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
+        "v_mad_u64_u32 %0, vcc, %5, %8, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %5, %9, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %2, %12, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %2, %13, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, %12, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %3, %13, %1"
+        : "=&v"(E), "=&v"(M), "=&v"(h0), "=&v"(h1)
+        : "v"((u32)x), "v"((u32)(x >> 32)), "v"((u32)W0), "v"((u32)(W0 >> 32)), "v"((u32)W1), "v"((u32)(W1 >> 32)),
+          "v"(Q0), "v"(Q1), "v"((u32)nq), "v"((u32)(nq >> 32))
+        : "vcc");
+    const u32 hi = (u32)(E >> 32) + (u32)M;
+    return ((u64)hi << 32) | (u32)E;
+}
+
+__device__ __forceinline__ u64 mul_split(u64 x, const MulOp3 &w, u64 nq)
+{
+    return mul_split(x, w.w0, w.w1, w.q0, w.q1, nq);
+}
+
+// Per-modulus constants of the NTT kernels (both arithmetic flavours)
+struct __attribute__((aligned(16))) NttMod
+{
+    u64 q;
+    u64 pad;
+    MulOp inv_n;    // n^-1 mod q                              (util/ntt.cpp:289-295)
+    MulOp inv_n_w;  // inv_root_powers[n-1] * n^-1 mod q      (util/ntt.h:50-56)
+    MulOp3 inv_n3;
+    MulOp3 inv_n_w3;
+};
+
 // Limb position -> modulus index map, passed to kernels by value (CAT_MAX_MODULI entries).
 struct LimbMap
 {

@@ -2,8 +2,7 @@
 //
 // Replaces util::ntt_negacyclic_harvey[_lazy] (util/ntt.cpp:393-436, util/dwthandler.h:94-192) and
 // util::inverse_ntt_negacyclic_harvey[_lazy] (util/ntt.cpp:438-474, util/dwthandler.h:203-357).
-// The butterfly network, twiddle order and lazy ranges are SEAL's, so even the *_lazy outputs are the
-// reference's exact representatives; only the schedule is new:
+// The butterfly network and twiddle order are SEAL's; only the schedule is new:
 //
 //   N = N1 x 256 (N >= 4096).  A limb-polynomial is viewed as N1 rows of 256 words.
 //   forward : "cols" kernel (first log2 N1 stages, stride-256 butterflies, tile = all N1 rows x C
@@ -15,7 +14,17 @@
 //   that global loads/stores are 128-byte contiguous per 16 lanes).
 //   N < 4096: one workgroup per limb-polynomial, stage-by-stage in LDS (tests / tiny parameters).
 //
-// HBM-bound by design: 16 B/coefficient algorithmic, twiddles (16 B each) come from L2.
+// Two arithmetic flavours share the kernels (policy template parameter):
+//   Exact : SEAL's Harvey butterflies with the 64-bit Shoup product (lazy range K = 2q).  Every intermediate
+//           value, hence every *_lazy output, is the reference's exact representative.  Used for the C ABI's
+//           lazy calls.
+//   Fast  : the same network with the split-Shoup product of modarith.cuh (r < 4q, lazy range K = 4q) and the
+//           same output contracts (forward lazy < 4q, inverse lazy < 2q, otherwise canonical).  Values agree
+//           with Exact modulo q everywhere, so canonical outputs are bit-identical; it needs ~25 % fewer VALU
+//           cycles per butterfly, which is what bounds these kernels.  Used for fully
+//           reduced transforms and by every internal caller (key switching, rescale, BFV multiply).
+//
+// HBM traffic is 16 B/coefficient per pass (two passes); twiddles come from L2.
 #include "context.hpp"
 
 namespace
@@ -27,8 +36,8 @@ namespace
     struct NttArgs
     {
         u64 *data;
-        const DevMod *mods;
-        const MulOp *tw; // [n_mod][n]
+        const NttMod *mods;
+        const void *tw; // Exact: MulOp [n_mod][n];  Fast: u64 [n_mod][3][n] (w0 | w1 | q0,q1)
         LimbMap map;
         u32 n_limbs;
         u32 n_polys;
@@ -61,58 +70,192 @@ namespace
         return w;
     }
 
-    __device__ __forceinline__ u64 guard2(u64 x, u64 q2)
+    // x >= K ? x - K : x   (one 64-bit add, one compare, two selects)
+    __device__ __forceinline__ u64 guard(u64 x, u64 K, u64 negK)
     {
-        return x >= q2 ? x - q2 : x;
+        const u64 t = x + negK;
+        return x >= K ? t : x;
     }
+
+    // ---- arithmetic policies ----------------------------------------------------------------------------
+    struct Exact
+    {
+        typedef MulOp Tw;
+        typedef const MulOp *Table;
+        struct Mod
+        {
+            u64 q, K, negK;
+            MulOp inv_n, inv_n_w;
+        };
+        static constexpr bool fast = false;
+        __device__ static __forceinline__ Mod mod(const NttMod &m)
+        {
+            Mod r;
+            r.q = m.q;
+            r.K = m.q << 1;
+            r.negK = 0 - r.K;
+            r.inv_n = m.inv_n;
+            r.inv_n_w = m.inv_n_w;
+            return r;
+        }
+        __device__ static __forceinline__ Table table(const void *tw, u32 mod, u32 log_n, bool)
+        {
+            return reinterpret_cast<const MulOp *>(tw) + ((size_t)mod << log_n);
+        }
+        template <int CNT>
+        __device__ static __forceinline__ void load(Table t, u32 idx, Tw (&w)[CNT])
+        {
+#pragma unroll
+            for (int g = 0; g < CNT; ++g)
+                w[g] = t[idx + g];
+        }
+        __device__ static __forceinline__ u64 mul(u64 x, const Tw &w, const Mod &m)
+        {
+            return mul_lazy(x, w, m.q);
+        }
+        __device__ static __forceinline__ Tw inv_n(const Mod &m) { return m.inv_n; }
+        __device__ static __forceinline__ Tw inv_n_w(const Mod &m) { return m.inv_n_w; }
+        // forward values are < 2K = 4q, inverse values < K = 2q
+        __device__ static __forceinline__ u64 finish_fwd(u64 x, const Mod &m, bool lazy)
+        {
+            return lazy ? x : csub(csub(x, m.K), m.q);
+        }
+        __device__ static __forceinline__ u64 finish_inv(u64 x, const Mod &m, bool lazy)
+        {
+            return lazy ? x : csub(x, m.q);
+        }
+    };
+
+    struct Fast
+    {
+        typedef MulOp3 Tw;
+        struct Table
+        {
+            const u64 *w0, *w1, *qq;
+        };
+        struct Mod
+        {
+            u64 q, K, negK, nq;
+            MulOp3 inv_n, inv_n_w;
+        };
+        static constexpr bool fast = true;
+        __device__ static __forceinline__ Mod mod(const NttMod &m)
+        {
+            Mod r;
+            r.q = m.q;
+            r.K = m.q << 2;
+            r.negK = 0 - r.K;
+            r.nq = 0 - m.q;
+            r.inv_n = m.inv_n3;
+            r.inv_n_w = m.inv_n_w3;
+            return r;
+        }
+        // the inverse table is stored shifted by one entry (entry j = inv_root_powers[j + 1]) so that every
+        // group of 2, 4 or 8 consecutive twiddles starts 16-byte aligned
+        __device__ static __forceinline__ Table table(const void *tw, u32 mod, u32 log_n, bool inverse)
+        {
+            const u64 *b = reinterpret_cast<const u64 *>(tw) + ((size_t)mod * 3 << log_n) - (inverse ? 1 : 0);
+            Table t;
+            t.w0 = b;
+            t.w1 = b + ((size_t)1 << log_n);
+            t.qq = b + ((size_t)2 << log_n);
+            return t;
+        }
+        template <int CNT>
+        __device__ static __forceinline__ void load(const Table &t, u32 idx, Tw (&w)[CNT])
+        {
+            if (CNT == 1)
+            {
+                const u64 qq = t.qq[idx];
+                w[0].w0 = t.w0[idx];
+                w[0].w1 = t.w1[idx];
+                w[0].q0 = (u32)qq;
+                w[0].q1 = (u32)(qq >> 32);
+            }
+            else
+            {
+#pragma unroll
+                for (int g = 0; g < CNT; g += 2)
+                {
+                    const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(t.w0 + idx + g);
+                    const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(t.w1 + idx + g);
+                    const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(t.qq + idx + g);
+                    w[g].w0 = a.x, w[g].w1 = b.x, w[g].q0 = (u32)c.x, w[g].q1 = (u32)(c.x >> 32);
+                    w[g + 1].w0 = a.y, w[g + 1].w1 = b.y, w[g + 1].q0 = (u32)c.y, w[g + 1].q1 = (u32)(c.y >> 32);
+                }
+            }
+        }
+        __device__ static __forceinline__ u64 mul(u64 x, const Tw &w, const Mod &m)
+        {
+            return mul_split(x, w, m.nq);
+        }
+        __device__ static __forceinline__ Tw inv_n(const Mod &m) { return m.inv_n; }
+        __device__ static __forceinline__ Tw inv_n_w(const Mod &m) { return m.inv_n_w; }
+        // forward values are < 2K = 8q, inverse values < K = 4q; contracts: lazy forward < 4q, lazy inverse < 2q
+        __device__ static __forceinline__ u64 finish_fwd(u64 x, const Mod &m, bool lazy)
+        {
+            x = csub(x, m.K);
+            return lazy ? x : csub(csub(x, m.q << 1), m.q);
+        }
+        __device__ static __forceinline__ u64 finish_inv(u64 x, const Mod &m, bool lazy)
+        {
+            x = csub(x, m.q << 1);
+            return lazy ? x : csub(x, m.q);
+        }
+    };
 
     // ---- 16-point register networks ---------------------------------------------------------------
     // Forward (Cooley-Tukey) local stage S: register gap 8 >> S, 2^S twiddles tw[(base << S) + g].
-    template <int S>
-    __device__ __forceinline__ void fwd_stage16(u64 (&x)[16], const MulOp *__restrict__ tw, u32 base, u64 q, u64 q2)
+    template <class P, int S>
+    __device__ __forceinline__ void fwd_stage16(u64 (&x)[16], const typename P::Table &tw, u32 base,
+                                                const typename P::Mod &m)
     {
         constexpr int gap = 8 >> S;
+        typename P::Tw w[1 << S];
+        P::template load<(1 << S)>(tw, base << S, w);
 #pragma unroll
         for (int g = 0; g < (1 << S); ++g)
         {
-            const MulOp w = tw[(base << S) + g];
 #pragma unroll
             for (int j = 0; j < gap; ++j)
             {
                 const int i0 = g * 2 * gap + j;
-                const u64 u = guard2(x[i0], q2);
-                const u64 v = mul_lazy(x[i0 + gap], w, q);
+                const u64 u = guard(x[i0], m.K, m.negK);
+                const u64 v = P::mul(x[i0 + gap], w[g], m);
                 x[i0] = u + v;
-                x[i0 + gap] = u + q2 - v;
+                x[i0 + gap] = u + m.K - v;
             }
         }
     }
 
     // Inverse (Gentleman-Sande) local stage S: register gap 1 << S, 8 >> S twiddles tw[root0 + g].
-    template <int S>
-    __device__ __forceinline__ void inv_stage16(u64 (&x)[16], const MulOp *__restrict__ tw, u32 root0, u64 q, u64 q2)
+    template <class P, int S>
+    __device__ __forceinline__ void inv_stage16(u64 (&x)[16], const typename P::Table &tw, u32 root0,
+                                                const typename P::Mod &m)
     {
         constexpr int gap = 1 << S;
+        typename P::Tw w[8 >> S];
+        P::template load<(8 >> S)>(tw, root0, w);
 #pragma unroll
         for (int g = 0; g < (8 >> S); ++g)
         {
-            const MulOp w = tw[root0 + g];
 #pragma unroll
             for (int j = 0; j < gap; ++j)
             {
                 const int i0 = g * 2 * gap + j;
                 const u64 u = x[i0], v = x[i0 + gap];
-                x[i0] = guard2(u + v, q2);
-                x[i0 + gap] = mul_lazy(u + q2 - v, w, q);
+                x[i0] = guard(u + v, m.K, m.negK);
+                x[i0 + gap] = P::mul(u + m.K - v, w[g], m);
             }
         }
     }
 
     // Final inverse stage (single twiddle, merged n^-1): dwthandler.h:274-315.
-    template <int S>
-    __device__ __forceinline__ void inv_last_stage16(u64 (&x)[16], const DevMod &m, u64 q2)
+    template <class P, int S>
+    __device__ __forceinline__ void inv_last_stage16(u64 (&x)[16], const typename P::Mod &m)
     {
         constexpr int gap = 1 << S;
+        const typename P::Tw wn = P::inv_n(m), wnw = P::inv_n_w(m);
 #pragma unroll
         for (int g = 0; g < (8 >> S); ++g)
         {
@@ -120,15 +263,15 @@ namespace
             for (int j = 0; j < gap; ++j)
             {
                 const int i0 = g * 2 * gap + j;
-                const u64 u = guard2(x[i0], q2), v = x[i0 + gap];
-                x[i0] = mul_lazy(guard2(u + v, q2), m.inv_n_op, m.inv_n_quo, m.q);
-                x[i0 + gap] = mul_lazy(u + q2 - v, m.inv_n_w_op, m.inv_n_w_quo, m.q);
+                const u64 u = guard(x[i0], m.K, m.negK), v = x[i0 + gap];
+                x[i0] = P::mul(guard(u + v, m.K, m.negK), wn, m);
+                x[i0 + gap] = P::mul(u + m.K - v, wnw, m);
             }
         }
     }
 
     // ---- forward, pass 1: columns ----------------------------------------------------------------------
-    template <int LOGN1>
+    template <class P, int LOGN1>
     __global__ __launch_bounds__(256) void ntt_fwd_cols(NttArgs a)
     {
         constexpr int K1 = LOGN1 - 4;          // stages done in round 1
@@ -140,9 +283,8 @@ namespace
         const Where w = locate(a, blockIdx.x, ROW_LEN / C);
         if (w.skip)
             return;
-        const DevMod m = a.mods[w.mod];
-        const u64 q = m.q, q2 = q << 1;
-        const MulOp *tw = a.tw + ((size_t)w.mod << a.log_n);
+        const typename P::Mod m = P::mod(a.mods[w.mod]);
+        const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, false);
         u64 *p = a.data + w.offset + w.tile * C;
 
         const u32 c = threadIdx.x % C, tau = threadIdx.x / C;
@@ -155,10 +297,10 @@ namespace
                 const u32 row = (e >> (4 - K1)) * 16 + tau * SUB + (e & (SUB - 1));
                 x[e] = p[row * ROW_LEN + c];
             }
-            if (K1 > 0) fwd_stage16<0>(x, tw, 1, q, q2);
-            if (K1 > 1) fwd_stage16<1>(x, tw, 1, q, q2);
-            if (K1 > 2) fwd_stage16<2>(x, tw, 1, q, q2);
-            if (K1 > 3) fwd_stage16<3>(x, tw, 1, q, q2);
+            if (K1 > 0) fwd_stage16<P, 0>(x, tw, 1, m);
+            if (K1 > 1) fwd_stage16<P, 1>(x, tw, 1, m);
+            if (K1 > 2) fwd_stage16<P, 2>(x, tw, 1, m);
+            if (K1 > 3) fwd_stage16<P, 3>(x, tw, 1, m);
 #pragma unroll
             for (int e = 0; e < 16; ++e)
             {
@@ -177,16 +319,17 @@ namespace
                 x[l] = p[(tau * 16 + l) * ROW_LEN + c];
         }
         const u32 base = (1u << K1) + tau;
-        fwd_stage16<0>(x, tw, base, q, q2);
-        fwd_stage16<1>(x, tw, base, q, q2);
-        fwd_stage16<2>(x, tw, base, q, q2);
-        fwd_stage16<3>(x, tw, base, q, q2);
+        fwd_stage16<P, 0>(x, tw, base, m);
+        fwd_stage16<P, 1>(x, tw, base, m);
+        fwd_stage16<P, 2>(x, tw, base, m);
+        fwd_stage16<P, 3>(x, tw, base, m);
 #pragma unroll
         for (int l = 0; l < 16; ++l)
             p[(tau * 16 + l) * ROW_LEN + c] = x[l];
     }
 
     // ---- forward, pass 2: rows (16 rows of 256 per workgroup) -------------------------------------------
+    template <class P>
     __global__ __launch_bounds__(256) void ntt_fwd_rows(NttArgs a)
     {
         __shared__ u64 lds[16 * ROW_PITCH];
@@ -194,9 +337,8 @@ namespace
         const Where w = locate(a, blockIdx.x, n1 / 16);
         if (w.skip)
             return;
-        const DevMod m = a.mods[w.mod];
-        const u64 q = m.q, q2 = q << 1;
-        const MulOp *tw = a.tw + ((size_t)w.mod << a.log_n);
+        const typename P::Mod m = P::mod(a.mods[w.mod]);
+        const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, false);
         const u32 r = threadIdx.x >> 4, t = threadIdx.x & 15;
         const u32 row = w.tile * 16 + r;
         u64 *p = a.data + w.offset + (size_t)row * ROW_LEN;
@@ -207,10 +349,10 @@ namespace
         for (int h = 0; h < 16; ++h)
             x[h] = p[h * 16 + t];
         const u32 base1 = n1 + row;
-        fwd_stage16<0>(x, tw, base1, q, q2);
-        fwd_stage16<1>(x, tw, base1, q, q2);
-        fwd_stage16<2>(x, tw, base1, q, q2);
-        fwd_stage16<3>(x, tw, base1, q, q2);
+        fwd_stage16<P, 0>(x, tw, base1, m);
+        fwd_stage16<P, 1>(x, tw, base1, m);
+        fwd_stage16<P, 2>(x, tw, base1, m);
+        fwd_stage16<P, 3>(x, tw, base1, m);
 #pragma unroll
         for (int h = 0; h < 16; ++h)
             s[h * 17 + t] = x[h];
@@ -219,16 +361,13 @@ namespace
         for (int l = 0; l < 16; ++l)
             x[l] = s[t * 17 + l];
         const u32 base2 = base1 * 16 + t;
-        fwd_stage16<0>(x, tw, base2, q, q2);
-        fwd_stage16<1>(x, tw, base2, q, q2);
-        fwd_stage16<2>(x, tw, base2, q, q2);
-        fwd_stage16<3>(x, tw, base2, q, q2);
-        if (!a.lazy)
-        {
+        fwd_stage16<P, 0>(x, tw, base2, m);
+        fwd_stage16<P, 1>(x, tw, base2, m);
+        fwd_stage16<P, 2>(x, tw, base2, m);
+        fwd_stage16<P, 3>(x, tw, base2, m);
 #pragma unroll
-            for (int l = 0; l < 16; ++l)
-                x[l] = csub(guard2(x[l], q2), q);
-        }
+        for (int l = 0; l < 16; ++l)
+            x[l] = P::finish_fwd(x[l], m, a.lazy != 0);
         __syncthreads();
 #pragma unroll
         for (int l = 0; l < 16; ++l)
@@ -240,6 +379,7 @@ namespace
     }
 
     // ---- inverse, pass 1: rows ---------------------------------------------------------------------------
+    template <class P>
     __global__ __launch_bounds__(256) void ntt_inv_rows(NttArgs a)
     {
         __shared__ u64 lds[16 * ROW_PITCH];
@@ -247,9 +387,8 @@ namespace
         const Where w = locate(a, blockIdx.x, n1 / 16);
         if (w.skip)
             return;
-        const DevMod m = a.mods[w.mod];
-        const u64 q = m.q, q2 = q << 1;
-        const MulOp *tw = a.tw + ((size_t)w.mod << a.log_n);
+        const typename P::Mod m = P::mod(a.mods[w.mod]);
+        const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, true);
         const u32 r = threadIdx.x >> 4, t = threadIdx.x & 15;
         const u32 row = w.tile * 16 + r;
         u64 *p = a.data + w.offset + (size_t)row * ROW_LEN;
@@ -265,10 +404,10 @@ namespace
             x[l] = s[t * 17 + l];
         // global stages 0..3: root index n - (n >> T) + 1 + group
         const u32 blk = row * 16 + t;
-        inv_stage16<0>(x, tw, n - (n >> 0) + 1 + blk * 8, q, q2);
-        inv_stage16<1>(x, tw, n - (n >> 1) + 1 + blk * 4, q, q2);
-        inv_stage16<2>(x, tw, n - (n >> 2) + 1 + blk * 2, q, q2);
-        inv_stage16<3>(x, tw, n - (n >> 3) + 1 + blk * 1, q, q2);
+        inv_stage16<P, 0>(x, tw, n - (n >> 0) + 1 + blk * 8, m);
+        inv_stage16<P, 1>(x, tw, n - (n >> 1) + 1 + blk * 4, m);
+        inv_stage16<P, 2>(x, tw, n - (n >> 2) + 1 + blk * 2, m);
+        inv_stage16<P, 3>(x, tw, n - (n >> 3) + 1 + blk * 1, m);
         __syncthreads();
 #pragma unroll
         for (int l = 0; l < 16; ++l)
@@ -278,17 +417,17 @@ namespace
         for (int h = 0; h < 16; ++h)
             x[h] = s[h * 17 + t];
         // global stages 4..7
-        inv_stage16<0>(x, tw, n - (n >> 4) + 1 + row * 8, q, q2);
-        inv_stage16<1>(x, tw, n - (n >> 5) + 1 + row * 4, q, q2);
-        inv_stage16<2>(x, tw, n - (n >> 6) + 1 + row * 2, q, q2);
-        inv_stage16<3>(x, tw, n - (n >> 7) + 1 + row * 1, q, q2);
+        inv_stage16<P, 0>(x, tw, n - (n >> 4) + 1 + row * 8, m);
+        inv_stage16<P, 1>(x, tw, n - (n >> 5) + 1 + row * 4, m);
+        inv_stage16<P, 2>(x, tw, n - (n >> 6) + 1 + row * 2, m);
+        inv_stage16<P, 3>(x, tw, n - (n >> 7) + 1 + row * 1, m);
 #pragma unroll
         for (int h = 0; h < 16; ++h)
             p[h * 16 + t] = x[h];
     }
 
     // ---- inverse, pass 2: columns --------------------------------------------------------------------------
-    template <int LOGN1>
+    template <class P, int LOGN1>
     __global__ __launch_bounds__(256) void ntt_inv_cols(NttArgs a)
     {
         constexpr int K1 = LOGN1 - 4;
@@ -301,9 +440,8 @@ namespace
         const Where w = locate(a, blockIdx.x, ROW_LEN / C);
         if (w.skip)
             return;
-        const DevMod m = a.mods[w.mod];
-        const u64 q = m.q, q2 = q << 1;
-        const MulOp *tw = a.tw + ((size_t)w.mod << a.log_n);
+        const typename P::Mod m = P::mod(a.mods[w.mod]);
+        const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, true);
         u64 *p = a.data + w.offset + w.tile * C;
         const u32 c = threadIdx.x % C, tau = threadIdx.x / C;
 
@@ -312,13 +450,13 @@ namespace
         for (int l = 0; l < 16; ++l)
             x[l] = p[(tau * 16 + l) * ROW_LEN + c];
         // global stages 8..11
-        inv_stage16<0>(x, tw, n - (n >> 8) + 1 + tau * 8, q, q2);
-        inv_stage16<1>(x, tw, n - (n >> 9) + 1 + tau * 4, q, q2);
-        inv_stage16<2>(x, tw, n - (n >> 10) + 1 + tau * 2, q, q2);
+        inv_stage16<P, 0>(x, tw, n - (n >> 8) + 1 + tau * 8, m);
+        inv_stage16<P, 1>(x, tw, n - (n >> 9) + 1 + tau * 4, m);
+        inv_stage16<P, 2>(x, tw, n - (n >> 10) + 1 + tau * 2, m);
         if (K1 == 0)
-            inv_last_stage16<3>(x, m, q2);
+            inv_last_stage16<P, 3>(x, m);
         else
-            inv_stage16<3>(x, tw, n - (n >> 11) + 1 + tau, q, q2);
+            inv_stage16<P, 3>(x, tw, n - (n >> 11) + 1 + tau, m);
         if (K1 > 0)
         {
 #pragma unroll
@@ -332,20 +470,17 @@ namespace
                 x[e] = lds[row * C + c];
             }
             // global stages 12 .. 12+K1-1 act on register stages S = 4-K1 .. 3; the last one is final
-            if (K1 == 4) inv_stage16<0>(x, tw, n - (n >> 12) + 1, q, q2);
-            if (K1 == 3) inv_stage16<1>(x, tw, n - (n >> 12) + 1, q, q2);
-            if (K1 == 4) inv_stage16<1>(x, tw, n - (n >> 13) + 1, q, q2);
-            if (K1 == 2) inv_stage16<2>(x, tw, n - (n >> 12) + 1, q, q2);
-            if (K1 == 3) inv_stage16<2>(x, tw, n - (n >> 13) + 1, q, q2);
-            if (K1 == 4) inv_stage16<2>(x, tw, n - (n >> 14) + 1, q, q2);
-            inv_last_stage16<3>(x, m, q2);
+            if (K1 == 4) inv_stage16<P, 0>(x, tw, n - (n >> 12) + 1, m);
+            if (K1 == 3) inv_stage16<P, 1>(x, tw, n - (n >> 12) + 1, m);
+            if (K1 == 4) inv_stage16<P, 1>(x, tw, n - (n >> 13) + 1, m);
+            if (K1 == 2) inv_stage16<P, 2>(x, tw, n - (n >> 12) + 1, m);
+            if (K1 == 3) inv_stage16<P, 2>(x, tw, n - (n >> 13) + 1, m);
+            if (K1 == 4) inv_stage16<P, 2>(x, tw, n - (n >> 14) + 1, m);
+            inv_last_stage16<P, 3>(x, m);
         }
-        if (!a.lazy)
-        {
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                x[e] = csub(x[e], q);
-        }
+        for (int e = 0; e < 16; ++e)
+            x[e] = P::finish_inv(x[e], m, a.lazy != 0);
         if (K1 > 0)
         {
 #pragma unroll
@@ -364,7 +499,7 @@ namespace
     }
 
     // ---- small N (< 4096): one workgroup per limb-polynomial, stage by stage in LDS -----------------------
-    template <bool FWD>
+    template <class P, bool FWD>
     __global__ __launch_bounds__(256) void ntt_small(NttArgs a)
     {
         __shared__ u64 s[2048];
@@ -372,13 +507,13 @@ namespace
         const Where w = locate(a, blockIdx.x, 1);
         if (w.skip)
             return;
-        const DevMod m = a.mods[w.mod];
-        const u64 q = m.q, q2 = q << 1;
-        const MulOp *tw = a.tw + ((size_t)w.mod << a.log_n);
+        const typename P::Mod m = P::mod(a.mods[w.mod]);
+        const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, !FWD);
         u64 *p = a.data + w.offset;
         for (u32 i = threadIdx.x; i < n; i += blockDim.x)
             s[i] = p[i];
         __syncthreads();
+        typename P::Tw tv[1];
         if (FWD)
         {
             u32 lg = a.log_n - 1; // log2(gap)
@@ -388,15 +523,15 @@ namespace
                 {
                     const u32 i = j >> lg, pos = j & ((1u << lg) - 1);
                     const u32 i0 = (i << (lg + 1)) + pos, i1 = i0 + (1u << lg);
-                    const MulOp w = tw[mm + i];
-                    const u64 u = guard2(s[i0], q2), v = mul_lazy(s[i1], w, q);
+                    P::template load<1>(tw, mm + i, tv);
+                    const u64 u = guard(s[i0], m.K, m.negK), v = P::mul(s[i1], tv[0], m);
                     s[i0] = u + v;
-                    s[i1] = u + q2 - v;
+                    s[i1] = u + m.K - v;
                 }
                 __syncthreads();
             }
             for (u32 i = threadIdx.x; i < n; i += blockDim.x)
-                p[i] = a.lazy ? s[i] : csub(guard2(s[i], q2), q);
+                p[i] = P::finish_fwd(s[i], m, a.lazy != 0);
         }
         else
         {
@@ -407,72 +542,48 @@ namespace
                 {
                     const u32 i = j >> lg, pos = j & ((1u << lg) - 1);
                     const u32 i0 = (i << (lg + 1)) + pos, i1 = i0 + (1u << lg);
-                    const MulOp w = tw[n - 2 * mm + 1 + i];
+                    P::template load<1>(tw, n - 2 * mm + 1 + i, tv);
                     const u64 u = s[i0], v = s[i1];
-                    s[i0] = guard2(u + v, q2);
-                    s[i1] = mul_lazy(u + q2 - v, w, q);
+                    s[i0] = guard(u + v, m.K, m.negK);
+                    s[i1] = P::mul(u + m.K - v, tv[0], m);
                 }
                 __syncthreads();
             }
+            const typename P::Tw wn = P::inv_n(m), wnw = P::inv_n_w(m);
             for (u32 j = threadIdx.x; j < half; j += blockDim.x)
             {
-                const u64 u = guard2(s[j], q2), v = s[j + half];
-                s[j] = mul_lazy(guard2(u + v, q2), m.inv_n_op, m.inv_n_quo, q);
-                s[j + half] = mul_lazy(u + q2 - v, m.inv_n_w_op, m.inv_n_w_quo, q);
+                const u64 u = guard(s[j], m.K, m.negK), v = s[j + half];
+                s[j] = P::mul(guard(u + v, m.K, m.negK), wn, m);
+                s[j + half] = P::mul(u + m.K - v, wnw, m);
             }
             __syncthreads();
             for (u32 i = threadIdx.x; i < n; i += blockDim.x)
-                p[i] = a.lazy ? s[i] : csub(s[i], q);
+                p[i] = P::finish_inv(s[i], m, a.lazy != 0);
         }
     }
 
-    template <int LOGN1>
+    template <class P, int LOGN1>
     void launch_cols(bool fwd, const NttArgs &a, u32 blocks, hipStream_t s)
     {
         if (fwd)
-            hipLaunchKernelGGL(ntt_fwd_cols<LOGN1>, dim3(blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((ntt_fwd_cols<P, LOGN1>), dim3(blocks), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL(ntt_inv_cols<LOGN1>, dim3(blocks), dim3(256), 0, s, a);
-    }
-} // namespace
-
-namespace cat
-{
-    cat_status launch_ntt(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
-                          uint32_t n_polys, bool lazy, hipStream_t s)
-    {
-        return launch_ntt_ex(ctx, forward, d_data, map, n_limbs, n_polys, lazy, (u64)n_limbs << ctx->log_n, 1, false,
-                             s);
+            hipLaunchKernelGGL((ntt_inv_cols<P, LOGN1>), dim3(blocks), dim3(256), 0, s, a);
     }
 
-    cat_status launch_ntt_ex(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
-                             uint32_t n_polys, bool lazy, u64 poly_stride, uint32_t limb_group, bool skip_diag,
-                             hipStream_t s)
+    template <class P>
+    cat_status launch_policy(cat_ctx *ctx, bool forward, NttArgs &a, hipStream_t s)
     {
-        if (n_limbs == 0 || n_polys == 0)
-            return CAT_OK;
-        NttArgs a;
-        a.data = d_data;
-        a.mods = ctx->d_mods;
-        a.tw = forward ? ctx->d_tw_fwd : ctx->d_tw_inv;
-        a.map = map;
-        a.n_limbs = n_limbs;
-        a.n_polys = n_polys;
-        a.log_n = ctx->log_n;
-        a.lazy = lazy ? 1 : 0;
-        a.poly_stride = poly_stride;
-        a.limb_group = limb_group;
-        a.skip_diag = skip_diag ? 1 : 0;
-        const uint64_t n_lp = (uint64_t)n_limbs * n_polys;
+        const uint64_t n_lp = (uint64_t)a.n_limbs * a.n_polys;
         if (ctx->log_n < 12)
         {
             if (n_lp > 0x7fffffffu)
-                return fail(CAT_ERR_LOGIC, "invalid parameters");
+                return cat::fail(CAT_ERR_LOGIC, "invalid parameters");
             const u32 threads = ctx->n / 2 >= 256 ? 256 : 64;
             if (forward)
-                hipLaunchKernelGGL(ntt_small<true>, dim3((u32)n_lp), dim3(threads), 0, s, a);
+                hipLaunchKernelGGL((ntt_small<P, true>), dim3((u32)n_lp), dim3(threads), 0, s, a);
             else
-                hipLaunchKernelGGL(ntt_small<false>, dim3((u32)n_lp), dim3(threads), 0, s, a);
+                hipLaunchKernelGGL((ntt_small<P, false>), dim3((u32)n_lp), dim3(threads), 0, s, a);
             CAT_HIP(hipGetLastError());
             return CAT_OK;
         }
@@ -481,28 +592,65 @@ namespace cat
         const uint64_t row_blocks = n_lp * (n1 / 16);
         const uint64_t col_blocks = n_lp * (ROW_LEN / (TILE_WORDS / n1));
         if (row_blocks > 0x7fffffffu || col_blocks > 0x7fffffffu)
-            return fail(CAT_ERR_LOGIC, "invalid parameters");
+            return cat::fail(CAT_ERR_LOGIC, "invalid parameters");
         auto cols = [&]() {
             switch (logn1)
             {
-            case 4: launch_cols<4>(forward, a, (u32)col_blocks, s); break;
-            case 5: launch_cols<5>(forward, a, (u32)col_blocks, s); break;
-            case 6: launch_cols<6>(forward, a, (u32)col_blocks, s); break;
-            case 7: launch_cols<7>(forward, a, (u32)col_blocks, s); break;
-            default: launch_cols<8>(forward, a, (u32)col_blocks, s); break;
+            case 4: launch_cols<P, 4>(forward, a, (u32)col_blocks, s); break;
+            case 5: launch_cols<P, 5>(forward, a, (u32)col_blocks, s); break;
+            case 6: launch_cols<P, 6>(forward, a, (u32)col_blocks, s); break;
+            case 7: launch_cols<P, 7>(forward, a, (u32)col_blocks, s); break;
+            default: launch_cols<P, 8>(forward, a, (u32)col_blocks, s); break;
             }
         };
         if (forward)
         {
             cols();
-            hipLaunchKernelGGL(ntt_fwd_rows, dim3((u32)row_blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((ntt_fwd_rows<P>), dim3((u32)row_blocks), dim3(256), 0, s, a);
         }
         else
         {
-            hipLaunchKernelGGL(ntt_inv_rows, dim3((u32)row_blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((ntt_inv_rows<P>), dim3((u32)row_blocks), dim3(256), 0, s, a);
             cols();
         }
         CAT_HIP(hipGetLastError());
         return CAT_OK;
+    }
+} // namespace
+
+namespace cat
+{
+    cat_status launch_ntt(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
+                          uint32_t n_polys, bool lazy, hipStream_t s, bool exact)
+    {
+        return launch_ntt_ex(ctx, forward, d_data, map, n_limbs, n_polys, lazy, (u64)n_limbs << ctx->log_n, 1, false,
+                             s, exact);
+    }
+
+    cat_status launch_ntt_ex(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
+                             uint32_t n_polys, bool lazy, u64 poly_stride, uint32_t limb_group, bool skip_diag,
+                             hipStream_t s, bool exact)
+    {
+        if (n_limbs == 0 || n_polys == 0)
+            return CAT_OK;
+        NttArgs a;
+        a.data = d_data;
+        a.mods = ctx->d_nttmods;
+        a.map = map;
+        a.n_limbs = n_limbs;
+        a.n_polys = n_polys;
+        a.log_n = ctx->log_n;
+        a.lazy = lazy ? 1 : 0;
+        a.poly_stride = poly_stride;
+        a.limb_group = limb_group;
+        a.skip_diag = skip_diag ? 1 : 0;
+        // N = 2 has odd-aligned twiddle groups nowhere, but keep the tiny sizes on the exact path: nothing to gain
+        if (exact || ctx->log_n < 2)
+        {
+            a.tw = forward ? (const void *)ctx->d_tw_fwd : (const void *)ctx->d_tw_inv;
+            return launch_policy<Exact>(ctx, forward, a, s);
+        }
+        a.tw = forward ? (const void *)ctx->d_tw3_fwd : (const void *)ctx->d_tw3_inv;
+        return launch_policy<Fast>(ctx, forward, a, s);
     }
 } // namespace cat

@@ -82,7 +82,7 @@ typedef void (*kfn)(u32 *, u32, u32, int);
 
 static void run(const char *name, kfn k, u32 *buf, int waves_per_simd)
 {
-    const int iters = 4000;
+    const int iters = 40000;
     const int blocks = 256 * waves_per_simd; // 256 CUs x 4 SIMDs x waves_per_simd waves, 4 waves per block
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
