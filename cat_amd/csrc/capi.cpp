@@ -205,7 +205,7 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
                 }
             }
             nm[i].q = hm.q;
-            nm[i].pad = 0;
+            nm[i].ratio1 = hm.ratio1;
             nm[i].inv_n = MulOp{ t.inv_n, hm.shoup(t.inv_n) };
             nm[i].inv_n_w = MulOp{ t.inv_n_w, hm.shoup(t.inv_n_w) };
             nm[i].inv_n3 = split3(hm, t.inv_n);

@@ -94,7 +94,7 @@ namespace cat
     // skip_diag skips limbs with j % limb_group == j / limb_group (key switching's I == J operands)
     cat_status launch_ntt_ex(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
                              uint32_t n_polys, bool lazy, u64 poly_stride, uint32_t limb_group, bool skip_diag,
-                             hipStream_t s, bool exact = false);
+                             hipStream_t s, bool exact = false, const u64 *raise_src = nullptr, u64 raise_src_stride = 0);
     cat_status launch_ew(cat_ctx *ctx, int op, const u64 *a, const u64 *b, u64 *out, const LimbMap &map,
                          uint32_t n_limbs, uint32_t n_polys, hipStream_t s);
     cat_status launch_scalar(cat_ctx *ctx, int op, const u64 *a, const u64 *scalars, u64 *out, const LimbMap &map,

@@ -14,44 +14,6 @@
 
 namespace
 {
-    struct RaiseArgs
-    {
-        const u64 *t_target; // [batch][d][N] coefficient form, canonical
-        u64 *ext;            // [batch][d+1][d][N]
-        const DevMod *mods;
-        u32 d, k, log_n;
-        int skip_diag;
-        u64 src_stride2; // vectors between consecutive t_target objects
-        u64 total2;      // batch*(d+1)*d*N/2
-    };
-
-    __global__ __launch_bounds__(256) void ks_raise_kernel(RaiseArgs g)
-    {
-        const u64 stride = (u64)gridDim.x * blockDim.x;
-        const u32 n2 = 1u << (g.log_n - 1);
-        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
-        {
-            const u32 c = (u32)(i & (n2 - 1));
-            u64 r = i >> (g.log_n - 1);
-            const u32 J = (u32)(r % g.d);
-            r /= g.d;
-            const u32 I = (u32)(r % (g.d + 1));
-            const u64 b = r / (g.d + 1);
-            if (g.skip_diag && I == J)
-                continue;
-            const u32 ki = I == g.d ? g.k - 1 : I;
-            const DevMod m = g.mods[ki];
-            const u64 qJ = g.mods[J].q;
-            ulonglong2 v = reinterpret_cast<const ulonglong2 *>(g.t_target)[b * g.src_stride2 + ((u64)J << (g.log_n - 1)) + c];
-            if (qJ > m.q)
-            {
-                v.x = barrett64(v.x, m.q, m.ratio1);
-                v.y = barrett64(v.y, m.q, m.ratio1);
-            }
-            reinterpret_cast<ulonglong2 *>(g.ext)[i] = v;
-        }
-    }
-
     struct MacArgs
     {
         const u64 *ext;    // [batch][d+1][d][N]
@@ -62,41 +24,69 @@ namespace
         u32 d, k, log_n;
         int use_diag;
         u64 target_stride; // words between consecutive target objects
-        u64 total;         // batch*(d+1)*N
+        u64 batch;
+        u64 total;         // ceil(batch / BB) * (d+1) * N/2 threads
     };
 
-    // one thread per (b, I, coefficient); both key components share the operand reads
+    // One thread per (batch tile, I, coefficient pair): the two key words of (J, component) are loaded once and
+    // used for BB ciphertexts of the batch, so the key (2 L (L+1) N words, the largest stream of the call) is
+    // read batch/BB times instead of batch times.
+    template <int BB>
     __global__ __launch_bounds__(256) void ks_mac_kernel(MacArgs g)
     {
-        const u64 stride = (u64)gridDim.x * blockDim.x;
-        const u32 n = 1u << g.log_n;
-        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total; i += stride)
+        const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+        if (i >= g.total)
+            return;
+        const u32 n2 = 1u << (g.log_n - 1);
+        const u32 c = (u32)(i & (n2 - 1));
+        const u64 r = i >> (g.log_n - 1);
+        const u32 I = (u32)(r % (g.d + 1));
+        const u64 b0 = (r / (g.d + 1)) * BB;
+        const u32 ki = I == g.d ? g.k - 1 : I;
+        const DevMod m = g.mods[ki];
+        u64 lo[BB][4], hi[BB][4]; // [b][comp * 2 + coefficient]
+#pragma unroll
+        for (int b = 0; b < BB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                lo[b][e] = hi[b][e] = 0;
+        const ulonglong2 *ext = reinterpret_cast<const ulonglong2 *>(g.ext) + c;
+        const ulonglong2 *tgt = reinterpret_cast<const ulonglong2 *>(g.target) + c;
+        const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(g.key) + ((u64)ki << (g.log_n - 1)) + c;
+        for (u32 J = 0; J < g.d; ++J)
         {
-            const u32 c = (u32)(i & (n - 1));
-            const u64 r = i >> g.log_n;
-            const u32 I = (u32)(r % (g.d + 1));
-            const u64 b = r / (g.d + 1);
-            const u32 ki = I == g.d ? g.k - 1 : I;
-            const DevMod m = g.mods[ki];
-            u64 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
-            const u64 *e = g.ext + (((b * (g.d + 1) + I) * g.d) << g.log_n) + c;
-            const u64 *kp = g.key + ((u64)ki << g.log_n) + c;
-            for (u32 J = 0; J < g.d; ++J)
+            const ulonglong2 k0 = kp[((u64)(J * 2 + 0) * g.k) << (g.log_n - 1)];
+            const ulonglong2 k1 = kp[((u64)(J * 2 + 1) * g.k) << (g.log_n - 1)];
+            const bool diag = g.use_diag && I == J;
+#pragma unroll
+            for (int b = 0; b < BB; ++b)
             {
-                u64 x;
-                if (g.use_diag && I == J)
-                    x = g.target[b * g.target_stride + ((u64)J << g.log_n) + c];
-                else
-                    x = e[(u64)J << g.log_n];
-                const u64 k0 = kp[((u64)(J * 2 + 0) * g.k) << g.log_n];
-                const u64 k1 = kp[((u64)(J * 2 + 1) * g.k) << g.log_n];
-                mac128(lo0, hi0, x, k0);
-                mac128(lo1, hi1, x, k1);
+                if (b0 + b < g.batch)
+                {
+                    const ulonglong2 x = diag ? tgt[(b0 + b) * (g.target_stride >> 1) + ((u64)J << (g.log_n - 1))]
+                                              : ext[((((b0 + b) * (g.d + 1) + I) * g.d + J) << (g.log_n - 1))];
+                    mac128(lo[b][0], hi[b][0], x.x, k0.x);
+                    mac128(lo[b][1], hi[b][1], x.y, k0.y);
+                    mac128(lo[b][2], hi[b][2], x.x, k1.x);
+                    mac128(lo[b][3], hi[b][3], x.y, k1.y);
+                }
             }
-            // d < 256: the reference's lazy counter never triggers an intermediate reduction (:2619-2707)
-            u64 *o = g.prod + (((b * 2) * (g.d + 1) + I) << g.log_n) + c;
-            o[0] = barrett128(lo0, hi0, m.q, m.ratio0, m.ratio1);
-            o[(u64)(g.d + 1) << g.log_n] = barrett128(lo1, hi1, m.q, m.ratio0, m.ratio1);
+        }
+        // d < 256: the reference's lazy counter never triggers an intermediate reduction (:2619-2707)
+#pragma unroll
+        for (int b = 0; b < BB; ++b)
+        {
+            if (b0 + b < g.batch)
+            {
+                ulonglong2 *o = reinterpret_cast<ulonglong2 *>(g.prod) + ((((b0 + b) * 2) * (g.d + 1) + I) << (g.log_n - 1)) + c;
+                ulonglong2 r0, r1;
+                r0.x = barrett128(lo[b][0], hi[b][0], m.q, m.ratio0, m.ratio1);
+                r0.y = barrett128(lo[b][1], hi[b][1], m.q, m.ratio0, m.ratio1);
+                r1.x = barrett128(lo[b][2], hi[b][2], m.q, m.ratio0, m.ratio1);
+                r1.y = barrett128(lo[b][3], hi[b][3], m.q, m.ratio0, m.ratio1);
+                o[0] = r0;
+                o[(u64)(g.d + 1) << (g.log_n - 1)] = r1;
+            }
         }
     }
 
@@ -328,24 +318,14 @@ namespace cat
                 return st;
             coeff_target = t_target;
         }
-        // step 2
+        // step 2: modulus raise fused into the first NTT pass (ntt.hip Source): ext is written once, already
+        // half transformed, instead of being written by a raise kernel and re-read
         {
-            RaiseArgs g;
-            g.t_target = coeff_target;
-            g.ext = ext;
-            g.mods = ctx->d_mods;
-            g.d = d;
-            g.k = k;
-            g.log_n = log_n;
-            g.skip_diag = ckks ? 1 : 0;
-            g.src_stride2 = (ckks ? (u64)d * N : (u64)target_stride) / 2;
-            g.total2 = w_ext / 2;
-            hipLaunchKernelGGL(ks_raise_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
-            CAT_HIP(hipGetLastError());
             LimbMap map{};
             for (u32 I = 0; I < rns; ++I)
                 map.id[I] = (unsigned char)(I == d ? k - 1 : I);
-            cat_status st = launch_ntt_ex(ctx, true, ext, map, rns * d, batch, true, (u64)rns * d * N, d, ckks, s);
+            cat_status st = launch_ntt_ex(ctx, true, ext, map, rns * d, batch, true, (u64)rns * d * N, d, ckks, s, false,
+                                          coeff_target, ckks ? (u64)d * N : (u64)target_stride);
             if (st != CAT_OK)
                 return st;
         }
@@ -362,8 +342,10 @@ namespace cat
             g.log_n = log_n;
             g.use_diag = ckks ? 1 : 0;
             g.target_stride = target_stride;
-            g.total = (u64)batch * rns * N;
-            hipLaunchKernelGGL(ks_mac_kernel, dim3(grid_for(g.total)), dim3(256), 0, s, g);
+            g.batch = batch;
+            constexpr int BB = 4;
+            g.total = (u64)((batch + BB - 1) / BB) * rns * (N / 2);
+            hipLaunchKernelGGL(ks_mac_kernel<BB>, dim3((u32)((g.total + 255) / 256)), dim3(256), 0, s, g);
             CAT_HIP(hipGetLastError());
         }
         // step 4

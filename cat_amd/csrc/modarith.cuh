@@ -124,27 +124,36 @@ struct __attribute__((aligned(8))) MulOp3
     u32 q1;
 };
 
-// nq = 2^64 - q
+// nq = 2^64 - q.  The high-word cross terms are accumulated first, shifted into the upper word, and the low-word
+// chain is accumulated on top: the result is born in one natural register pair (no recombination moves).
 __device__ __forceinline__ u64 mul_split(u64 x, u64 W0, u64 W1, u32 Q0, u32 Q1, u64 nq)
 {
-    u64 E, M;
+    u64 E;
     u32 h0, h1;
-    asm("v_mul_hi_u32 %2, %4, %10\n\t"
-        "v_mul_hi_u32 %3, %5, %11\n\t"
-        "v_mad_u64_u32 %0, vcc, %4, %6, 0\n\t"
-        "v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
-        "v_mad_u64_u32 %0, vcc, %5, %8, %0\n\t"
-        "v_mad_u64_u32 %1, vcc, %5, %9, %1\n\t"
+    asm("v_mul_hi_u32 %1, %3, %9\n\t"
+        "v_mul_hi_u32 %2, %4, %10\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, %6, 0\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %8, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %1, %12, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %2, %12, %0\n\t"
-        "v_mad_u64_u32 %1, vcc, %2, %13, %1\n\t"
-        "v_mad_u64_u32 %0, vcc, %3, %12, %0\n\t"
-        "v_mad_u64_u32 %1, vcc, %3, %13, %1"
-        : "=&v"(E), "=&v"(M), "=&v"(h0), "=&v"(h1)
+        "v_lshlrev_b64 %0, 32, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, %5, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %7, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %1, %11, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %2, %11, %0"
+        : "=&v"(E), "=&v"(h0), "=&v"(h1)
         : "v"((u32)x), "v"((u32)(x >> 32)), "v"((u32)W0), "v"((u32)(W0 >> 32)), "v"((u32)W1), "v"((u32)(W1 >> 32)),
           "v"(Q0), "v"(Q1), "v"((u32)nq), "v"((u32)(nq >> 32))
         : "vcc");
-    const u32 hi = (u32)(E >> 32) + (u32)M;
-    return ((u64)hi << 32) | (u32)E;
+    return E;
+}
+
+// 64-bit add as one v_lshl_add_u64 (the compiler prefers a two-instruction carry chain for x + constant)
+__device__ __forceinline__ u64 add64(u64 a, u64 b)
+{
+    u64 r;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 __device__ __forceinline__ u64 mul_split(u64 x, const MulOp3 &w, u64 nq)
@@ -156,7 +165,7 @@ __device__ __forceinline__ u64 mul_split(u64 x, const MulOp3 &w, u64 nq)
 struct __attribute__((aligned(16))) NttMod
 {
     u64 q;
-    u64 pad;
+    u64 ratio1;     // high word of floor(2^128/q): Barrett-64 of the fused modulus raise
     MulOp inv_n;    // n^-1 mod q                              (util/ntt.cpp:289-295)
     MulOp inv_n_w;  // inv_root_powers[n-1] * n^-1 mod q      (util/ntt.h:50-56)
     MulOp3 inv_n3;

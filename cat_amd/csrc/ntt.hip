@@ -46,6 +46,12 @@ namespace
         u64 poly_stride; // words between consecutive objects (>= n_limbs * n)
         u32 limb_group;  // limb j uses modulus map.id[j / limb_group]
         u32 skip_diag;   // skip limbs with j % limb_group == j / limb_group (already transformed)
+        // fused modulus raise of key switching (evaluator.cpp:2643-2651), forward only: when src != nullptr the
+        // first pass reads limb (j % limb_group) of object `poly` of src (coefficient form, canonical modulo
+        // prime j % limb_group), reduces it modulo the limb's own prime when that one is smaller, and writes the
+        // transformed limb to data as usual
+        const u64 *src;
+        u64 src_stride; // words between consecutive src objects
     };
 
     struct Where
@@ -54,6 +60,8 @@ namespace
         u32 mod;    // modulus index
         u32 tile;
         bool skip;
+        u64 src_offset; // fused raise: word offset of the source limb and its prime
+        u32 src_mod;
     };
 
     // limb is the slowest index so that concurrently running workgroups share one prime's twiddles in L2
@@ -67,14 +75,50 @@ namespace
         w.mod = a.map.id[grp];
         w.skip = a.skip_diag && (limb - grp * a.limb_group == grp);
         w.offset = (u64)poly * a.poly_stride + ((u64)limb << a.log_n);
+        w.src_mod = limb - grp * a.limb_group;
+        w.src_offset = (u64)poly * a.src_stride + ((u64)w.src_mod << a.log_n);
         return w;
     }
 
     // x >= K ? x - K : x   (one 64-bit add, one compare, two selects)
     __device__ __forceinline__ u64 guard(u64 x, u64 K, u64 negK)
     {
-        const u64 t = x + negK;
+        const u64 t = add64(x, negK);
         return x >= K ? t : x;
+    }
+
+    // Input side of a forward first pass: the data itself, or (fused raise) the source limb reduced modulo q.
+    struct Source
+    {
+        const u64 *p;
+        u64 q, ratio1;
+        bool reduce;
+        __device__ __forceinline__ u64 operator()(u32 i) const
+        {
+            const u64 v = p[i];
+            return reduce ? barrett64(v, q, ratio1) : v;
+        }
+    };
+
+    __device__ __forceinline__ Source source(const NttArgs &a, const Where &w, u64 extra)
+    {
+        Source s;
+        if (a.src)
+        {
+            const NttMod m = a.mods[w.mod];
+            s.p = a.src + w.src_offset + extra;
+            s.q = m.q;
+            s.ratio1 = m.ratio1;
+            s.reduce = a.mods[w.src_mod].q > m.q; // copy when q_J <= q_I (evaluator.cpp:2643)
+        }
+        else
+        {
+            s.p = a.data + w.offset + extra;
+            s.q = 0;
+            s.ratio1 = 0;
+            s.reduce = false;
+        }
+        return s;
     }
 
     // ---- arithmetic policies ----------------------------------------------------------------------------
@@ -87,7 +131,6 @@ namespace
             u64 q, K, negK;
             MulOp inv_n, inv_n_w;
         };
-        static constexpr bool fast = false;
         __device__ static __forceinline__ Mod mod(const NttMod &m)
         {
             Mod r;
@@ -138,7 +181,6 @@ namespace
             u64 q, K, negK, nq;
             MulOp3 inv_n, inv_n_w;
         };
-        static constexpr bool fast = true;
         __device__ static __forceinline__ Mod mod(const NttMod &m)
         {
             Mod r;
@@ -222,8 +264,8 @@ namespace
                 const int i0 = g * 2 * gap + j;
                 const u64 u = guard(x[i0], m.K, m.negK);
                 const u64 v = P::mul(x[i0 + gap], w[g], m);
-                x[i0] = u + v;
-                x[i0 + gap] = u + m.K - v;
+                x[i0] = add64(u, v);
+                x[i0 + gap] = add64(u, m.K) - v;
             }
         }
     }
@@ -244,8 +286,8 @@ namespace
             {
                 const int i0 = g * 2 * gap + j;
                 const u64 u = x[i0], v = x[i0 + gap];
-                x[i0] = guard(u + v, m.K, m.negK);
-                x[i0 + gap] = P::mul(u + m.K - v, w[g], m);
+                x[i0] = guard(add64(u, v), m.K, m.negK);
+                x[i0 + gap] = P::mul(add64(u, m.K) - v, w[g], m);
             }
         }
     }
@@ -264,8 +306,8 @@ namespace
             {
                 const int i0 = g * 2 * gap + j;
                 const u64 u = guard(x[i0], m.K, m.negK), v = x[i0 + gap];
-                x[i0] = P::mul(guard(u + v, m.K, m.negK), wn, m);
-                x[i0 + gap] = P::mul(u + m.K - v, wnw, m);
+                x[i0] = P::mul(guard(add64(u, v), m.K, m.negK), wn, m);
+                x[i0 + gap] = P::mul(add64(u, m.K) - v, wnw, m);
             }
         }
     }
@@ -286,6 +328,7 @@ namespace
         const typename P::Mod m = P::mod(a.mods[w.mod]);
         const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, false);
         u64 *p = a.data + w.offset + w.tile * C;
+        const Source in = source(a, w, w.tile * C);
 
         const u32 c = threadIdx.x % C, tau = threadIdx.x / C;
         u64 x[16];
@@ -295,7 +338,7 @@ namespace
             for (int e = 0; e < 16; ++e)
             {
                 const u32 row = (e >> (4 - K1)) * 16 + tau * SUB + (e & (SUB - 1));
-                x[e] = p[row * ROW_LEN + c];
+                x[e] = in(row * ROW_LEN + c);
             }
             if (K1 > 0) fwd_stage16<P, 0>(x, tw, 1, m);
             if (K1 > 1) fwd_stage16<P, 1>(x, tw, 1, m);
@@ -316,7 +359,7 @@ namespace
         {
 #pragma unroll
             for (int l = 0; l < 16; ++l)
-                x[l] = p[(tau * 16 + l) * ROW_LEN + c];
+                x[l] = in((tau * 16 + l) * ROW_LEN + c);
         }
         const u32 base = (1u << K1) + tau;
         fwd_stage16<P, 0>(x, tw, base, m);
@@ -510,8 +553,15 @@ namespace
         const typename P::Mod m = P::mod(a.mods[w.mod]);
         const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, !FWD);
         u64 *p = a.data + w.offset;
-        for (u32 i = threadIdx.x; i < n; i += blockDim.x)
-            s[i] = p[i];
+        if (FWD)
+        {
+            const Source in = source(a, w, 0);
+            for (u32 i = threadIdx.x; i < n; i += blockDim.x)
+                s[i] = in(i);
+        }
+        else
+            for (u32 i = threadIdx.x; i < n; i += blockDim.x)
+                s[i] = p[i];
         __syncthreads();
         typename P::Tw tv[1];
         if (FWD)
@@ -624,12 +674,12 @@ namespace cat
                           uint32_t n_polys, bool lazy, hipStream_t s, bool exact)
     {
         return launch_ntt_ex(ctx, forward, d_data, map, n_limbs, n_polys, lazy, (u64)n_limbs << ctx->log_n, 1, false,
-                             s, exact);
+                             s, exact, nullptr, 0);
     }
 
     cat_status launch_ntt_ex(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
                              uint32_t n_polys, bool lazy, u64 poly_stride, uint32_t limb_group, bool skip_diag,
-                             hipStream_t s, bool exact)
+                             hipStream_t s, bool exact, const u64 *raise_src, u64 raise_src_stride)
     {
         if (n_limbs == 0 || n_polys == 0)
             return CAT_OK;
@@ -644,6 +694,8 @@ namespace cat
         a.poly_stride = poly_stride;
         a.limb_group = limb_group;
         a.skip_diag = skip_diag ? 1 : 0;
+        a.src = forward ? raise_src : nullptr;
+        a.src_stride = raise_src_stride;
         // N = 2 has odd-aligned twiddle groups nowhere, but keep the tiny sizes on the exact path: nothing to gain
         if (exact || ctx->log_n < 2)
         {

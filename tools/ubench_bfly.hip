@@ -91,7 +91,8 @@ __device__ __forceinline__ u64 mulH(u64 x, u64 W0, u64 W1, u32 Q0, u32 Q1, u64 n
   return ((u64)hi<<32) | (u32)E;
 }
 
-template<int V> __global__ __launch_bounds__(256) void bfly(u64* out, const MulOp* tw, u64 q, int iters){
+template<int V> __global__ __launch_bounds__(256) void bfly(u64* out, const MulOp* tw, u64 q, int iters, long long* stamps){
+  long long c0 = clock64(), r0 = wall_clock64();
   u64 x[16]; const u64 q2=q<<1, nq=0-q, nq2=0-q2;
   for(int i=0;i<16;++i) x[i]=out[(size_t)(blockIdx.x*256+threadIdx.x)*16+i];
   for(int it=0;it<iters;++it){
@@ -117,11 +118,12 @@ template<int V> __global__ __launch_bounds__(256) void bfly(u64* out, const MulO
     x[15]=t0;
   }
   for(int i=0;i<16;++i) out[(size_t)(blockIdx.x*256+threadIdx.x)*16+i]=x[i];
+  if(threadIdx.x==0 && blockIdx.x==7){ stamps[0]=clock64()-c0; stamps[1]=wall_clock64()-r0; }
 }
 int main(){
   const u64 q = 1152921504606584833ULL;
   const int blocks = 256*8, iters = 4000;
-  u64* buf; MulOp* tw;
+  u64* buf; MulOp* tw; long long* stamps; CK(hipMalloc(&stamps, 16));
   CK(hipMalloc(&buf, (size_t)blocks*256*16*8)); CK(hipMalloc(&tw, 16*256*sizeof(MulOp)));
   std::vector<u64> h((size_t)blocks*256*16); u64 s=88172645463325252ULL;
   for(auto& v: h){ s^=s<<13; s^=s>>7; s^=s<<17; v = s % q; }
@@ -132,20 +134,22 @@ int main(){
   for(int v=0; v<8; ++v){
     CK(hipMemcpy(buf, h.data(), h.size()*8, hipMemcpyHostToDevice));
     hipEvent_t a,b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    auto launch=[&](int it){ if(v==0) hipLaunchKernelGGL(bfly<0>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it);
-                             else if(v==1) hipLaunchKernelGGL(bfly<1>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it);
-                             else if(v==6) hipLaunchKernelGGL(bfly<6>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it);
-                             else if(v==7) hipLaunchKernelGGL(bfly<7>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it);
-                             else if(v==4) hipLaunchKernelGGL(bfly<4>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it);
-                             else if(v==5) hipLaunchKernelGGL(bfly<5>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it);
-                             else if(v==3) hipLaunchKernelGGL(bfly<3>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it);
-                             else hipLaunchKernelGGL(bfly<2>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it); };
+    auto launch=[&](int it){ if(v==0) hipLaunchKernelGGL(bfly<0>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it, stamps);
+                             else if(v==1) hipLaunchKernelGGL(bfly<1>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it, stamps);
+                             else if(v==6) hipLaunchKernelGGL(bfly<6>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it, stamps);
+                             else if(v==7) hipLaunchKernelGGL(bfly<7>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it, stamps);
+                             else if(v==4) hipLaunchKernelGGL(bfly<4>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it, stamps);
+                             else if(v==5) hipLaunchKernelGGL(bfly<5>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it, stamps);
+                             else if(v==3) hipLaunchKernelGGL(bfly<3>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it, stamps);
+                             else hipLaunchKernelGGL(bfly<2>, dim3(blocks), dim3(256), 0, 0, buf, tw, q, it, stamps); };
     launch(iters); CK(hipDeviceSynchronize());
     CK(hipMemcpy(buf, h.data(), h.size()*8, hipMemcpyHostToDevice));
     CK(hipEventRecord(a)); launch(iters); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms,a,b));
     res[v].resize(h.size()); CK(hipMemcpy(res[v].data(), buf, h.size()*8, hipMemcpyDeviceToHost));
+    long long hs[2]; CK(hipMemcpy(hs, stamps, 16, hipMemcpyDeviceToHost));
     double nb=(double)blocks*256*8*iters;
+    printf("  in-kernel clock %.0f MHz  ", (double)hs[0]/(double)hs[1]*100.0);
     printf("variant %d: %.3f ms  %.1f Gbfly/s  -> cfg2 forward NTT VALU floor %.2f ms  same_as_v0=%d same_as_v6=%d\n", v, ms, nb/ms/1e6, 17.18e9/(nb/ms*1e3)*1e3, (int)(res[v]==res[0]), (int)(v>=6 && res[v]==res[6]));
   }
   return 0;
