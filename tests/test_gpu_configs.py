@@ -1,0 +1,116 @@
+"""GPU parity at the BASELINE.json configurations' own sizes (configs 2, 4, 5; config 1's parameters and config 3
+are in test_gpu_parity.py).  The oracle checks a subset it can finish in seconds; the rest of each batch is
+covered by size-independent properties (round trip, batch-position independence, linearity)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cat():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import cat_amd
+
+    return cat_amd
+
+
+def dev(a):
+    from cat_amd.api import to_device
+
+    return to_device(np.ascontiguousarray(a))
+
+
+def host(t):
+    from cat_amd.api import to_host
+
+    return to_host(t)
+
+
+def test_config2_batched_ntt_n65536_32_primes(cat, oracle):
+    """N=2^16, 32 60-bit primes = get_primes(2N, 60, 32) (numth.cpp:278-311), 128 of the 1024 polys here (bench.py
+    runs all 1024): forward output of 2 polys equals the oracle, every poly round-trips, and the transform is
+    linear modulo q (NTT(a) + NTT(b) = NTT(a + b))."""
+    import torch
+
+    log_n, n = 16, 65536
+    primes = oracle.get_primes(2 * n, 60, 32)
+    assert primes[0] == 1152921504606584833 and primes[-1] == 1152921504538951681
+    ctx = cat.Context(log_n, primes, cat.SCHEME_NONE)
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    polys = 128
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2)
+    x = torch.empty((polys, 32, n), dtype=torch.int64, device="cuda")
+    for j, q in enumerate(primes):
+        x[:, j, :] = torch.randint(0, q, (polys, n), dtype=torch.int64, device="cuda", generator=gen)
+    ref = x.clone()
+    ctx.ntt_forward(x)
+    sub = host(ref[:2])
+    assert (host(x[:2]) == octx.ntt_forward(sub, list(range(32)))).all()
+    # linearity on the whole batch: NTT(x[p] + x[p+1]) == NTT(x[p]) + NTT(x[p+1])
+    s = ctx.add(ref[0::2].contiguous(), ref[1::2].contiguous())
+    ctx.ntt_forward(s)
+    assert torch.equal(s, ctx.add(x[0::2].contiguous(), x[1::2].contiguous()))
+    ctx.ntt_inverse(x)
+    assert torch.equal(x, ref)
+    ctx.close()
+
+
+def test_config4_rotate_rescale_chain_n65536_L24(cat, oracle):
+    """CKKS N=2^16, 25 60-bit primes (24 ciphertext limbs + special), Galois key of step 1: rotate_vector then
+    rescale_to_next down three levels, batch of 3 with ciphertext 0 checked against the oracle at every step and
+    the other two (same input / other input) covering batch-position independence."""
+    log_n, n = 16, 65536
+    primes = list(reversed(oracle.get_primes(2 * n, 60, 25)))  # CoeffModulus::Create order (modulus.cpp:177-183)
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_CKKS)
+    sk = octx.secret_key(41)
+    elt = cat.galois_elt_from_step(log_n, 1)
+    assert elt == 3
+    gk = octx.galois_key(sk, elt, 42)
+    dgk = dev(gk)
+    L = 24
+    c0, c1 = octx.uniform(L, 2, 43), octx.uniform(L, 2, 44)
+    cur = dev(np.stack([c0, c1, c0]))
+    exp = c0
+    for _ in range(3):
+        ctx.rotate_vector(cur, 1, dgk)
+        exp = octx.apply_galois_inplace(exp, elt, gk)
+        assert (host(cur[0]) == exp).all(), f"rotate L={L}"
+        cur = ctx.rescale(cur)
+        exp = octx.rescale(exp)
+        assert (host(cur[0]) == exp).all(), f"rescale L={L}"
+        h = host(cur)
+        assert (h[2] == h[0]).all() and not (h[1] == h[0]).all()
+        L -= 1
+    ctx.close()
+
+
+def test_config5_batched_mul_relin_n32768(cat, oracle):
+    """CKKS N=2^15, BFVDefault(32768) = 16 primes (15 + special), one shared relinearization key: a 24-pair
+    slice of the 8192-pair batch (1024 per GPU at 8 GPUs); pairs 0 and 23 equal the oracle, repeated inputs give
+    repeated outputs wherever they sit in the batch."""
+    log_n, n = 15, 32768
+    primes = oracle.bfv_default(n)
+    assert len(primes) == 16
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_CKKS)
+    L = 15
+    rk = octx.relin_key(octx.secret_key(51), 52)
+    pool_x = [octx.uniform(L, 2, 60 + i) for i in range(3)]
+    pool_y = [octx.uniform(L, 2, 70 + i) for i in range(3)]
+    batch = 24
+    x = dev(np.stack([pool_x[i % 3] for i in range(batch)]))
+    y = dev(np.stack([pool_y[i % 3] for i in range(batch)]))
+    prod = ctx.ckks_multiply(x, y)
+    got = host(ctx.relinearize(prod, dev(rk)).contiguous())
+    for i in (0, 23):
+        e = octx.relinearize(octx.ckks_multiply(pool_x[i % 3], pool_y[i % 3]), rk)
+        assert (got[i] == e).all(), f"pair {i}"
+    for i in range(3, batch):
+        assert (got[i] == got[i % 3]).all(), f"batch position {i}"
+    ctx.close()
