@@ -80,6 +80,17 @@ namespace
         return w;
     }
 
+    // LDS hand-off between lanes of ONE wave (the rows kernels: a wave owns its 4 rows of the tile): LDS operations
+    // of a wave execute in order, so only the compiler has to be kept from reordering and the writes waited for;
+    // no s_barrier, the four waves of a workgroup drift freely and cover each other's memory waits.
+    __device__ __forceinline__ void wave_lds_sync()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
     // x >= K ? x - K : x   (one 64-bit add, one compare, two selects)
     __device__ __forceinline__ u64 guard(u64 x, u64 K, u64 negK)
     {
@@ -399,7 +410,7 @@ namespace
 #pragma unroll
         for (int h = 0; h < 16; ++h)
             s[h * 17 + t] = x[h];
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int l = 0; l < 16; ++l)
             x[l] = s[t * 17 + l];
@@ -411,11 +422,11 @@ namespace
 #pragma unroll
         for (int l = 0; l < 16; ++l)
             x[l] = P::finish_fwd(x[l], m, a.lazy != 0);
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int l = 0; l < 16; ++l)
             s[t * 17 + l] = x[l];
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int h = 0; h < 16; ++h)
             p[h * 16 + t] = s[h * 17 + t];
@@ -441,7 +452,7 @@ namespace
 #pragma unroll
         for (int h = 0; h < 16; ++h)
             s[h * 17 + t] = p[h * 16 + t];
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int l = 0; l < 16; ++l)
             x[l] = s[t * 17 + l];
@@ -451,11 +462,11 @@ namespace
         inv_stage16<P, 1>(x, tw, n - (n >> 1) + 1 + blk * 4, m);
         inv_stage16<P, 2>(x, tw, n - (n >> 2) + 1 + blk * 2, m);
         inv_stage16<P, 3>(x, tw, n - (n >> 3) + 1 + blk * 1, m);
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int l = 0; l < 16; ++l)
             s[t * 17 + l] = x[l];
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int h = 0; h < 16; ++h)
             x[h] = s[h * 17 + t];
