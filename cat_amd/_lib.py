@@ -43,6 +43,10 @@ SIGNATURES = {
     "cat_sub_scalar": (C.c_int, [vp, vp, u64p, vp, u32p, C.c_uint32, C.c_uint32, vp]),
     "cat_modulo": (C.c_int, [vp, vp, vp, u32p, C.c_uint32, C.c_uint32, vp]),
     "cat_ckks_multiply": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
+    "cat_ckks_square": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
+    "cat_multiply_plain_ntt": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
+    "cat_add_plain": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
+    "cat_sub_plain": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "cat_switch_key": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_relinearize": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_rescale": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),

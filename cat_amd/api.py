@@ -160,6 +160,31 @@ class Context:
         _check(self.lib.cat_ckks_multiply(self.h, self._p(x), self._p(y), self._p(out), L, b, self._stream()))
         return out
 
+    def ckks_square(self, x, out=None):
+        """x: [batch, 2, L, N] -> [batch, 3, L, N]"""
+        b, _, L, _ = x.shape
+        out = torch.empty((b, 3, L, self.n), dtype=torch.int64, device=x.device) if out is None else out
+        _check(self.lib.cat_ckks_square(self.h, self._p(x), self._p(out), L, b, self._stream()))
+        return out
+
+    def _plain(self, fn, ct, plain, out):
+        """ct: [batch, size, L, N]; plain: [L, N] (shared) or [batch, L, N]"""
+        b, size, L, _ = ct.shape
+        out = torch.empty_like(ct) if out is None else out
+        stride = 0 if plain.dim() == 2 else L * self.n
+        assert plain.shape[-2] == L and (plain.dim() == 2 or plain.shape[0] == b)
+        _check(fn(self.h, self._p(ct), self._p(plain), stride, self._p(out), L, size, b, self._stream()))
+        return out
+
+    def multiply_plain_ntt(self, ct, plain, out=None):
+        return self._plain(self.lib.cat_multiply_plain_ntt, ct, plain, out)
+
+    def add_plain(self, ct, plain, out=None):
+        return self._plain(self.lib.cat_add_plain, ct, plain, out)
+
+    def sub_plain(self, ct, plain, out=None):
+        return self._plain(self.lib.cat_sub_plain, ct, plain, out)
+
     def bfv_multiply(self, x, y, out=None):
         b, _, L, _ = x.shape
         out = torch.empty((b, 3, L, self.n), dtype=torch.int64, device=x.device) if out is None else out

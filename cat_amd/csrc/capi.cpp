@@ -513,6 +513,58 @@ cat_status cat_ckks_multiply(cat_ctx *ctx, const uint64_t *x, const uint64_t *y,
     return launch_ckks_tensor(ctx, (const u64 *)x, (const u64 *)y, (u64 *)out, L, batch, (hipStream_t)s);
 }
 
+cat_status cat_ckks_square(cat_ctx *ctx, const uint64_t *x, uint64_t *out, uint32_t L, uint32_t batch, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if ((st = level_check(ctx, L, false)) != CAT_OK)
+        return st;
+    if (batch && (!x || !out))
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (out == x)
+        return fail(CAT_ERR_INVALID_ARG, "destination must not alias the input");
+    return launch_ckks_square(ctx, (const u64 *)x, (u64 *)out, L, batch, (hipStream_t)s);
+}
+
+static cat_status plain_common(cat_ctx *ctx, int op, const uint64_t *ct, const uint64_t *plain, size_t plain_stride,
+                               uint64_t *out, uint32_t L, uint32_t size, uint32_t batch, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if ((st = level_check(ctx, L, false)) != CAT_OK)
+        return st;
+    if (size * batch == 0)
+        return CAT_OK;
+    if (!ct || !out)
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (!plain)
+        return fail(CAT_ERR_INVALID_ARG, "plain is not valid for encryption parameters");
+    if (plain_stride != 0 && (plain_stride < (size_t)L * ctx->n || (plain_stride & 1)))
+        return fail(CAT_ERR_INVALID_ARG, "stride");
+    return launch_plain(ctx, op, (const u64 *)ct, (const u64 *)plain, plain_stride, (u64 *)out, L, size, batch,
+                        (hipStream_t)s);
+}
+
+cat_status cat_multiply_plain_ntt(cat_ctx *ctx, const uint64_t *ct, const uint64_t *plain, size_t plain_stride,
+                                  uint64_t *out, uint32_t L, uint32_t size, uint32_t batch, cat_stream s)
+{
+    return plain_common(ctx, 0, ct, plain, plain_stride, out, L, size, batch, s);
+}
+
+cat_status cat_add_plain(cat_ctx *ctx, const uint64_t *ct, const uint64_t *plain, size_t plain_stride, uint64_t *out,
+                         uint32_t L, uint32_t size, uint32_t batch, cat_stream s)
+{
+    return plain_common(ctx, 1, ct, plain, plain_stride, out, L, size, batch, s);
+}
+
+cat_status cat_sub_plain(cat_ctx *ctx, const uint64_t *ct, const uint64_t *plain, size_t plain_stride, uint64_t *out,
+                         uint32_t L, uint32_t size, uint32_t batch, cat_stream s)
+{
+    return plain_common(ctx, 2, ct, plain, plain_stride, out, L, size, batch, s);
+}
+
 cat_status cat_switch_key(cat_ctx *ctx, uint64_t *enc, const uint64_t *target, const uint64_t *key, uint32_t L,
                           uint32_t batch, cat_stream s)
 {

@@ -101,6 +101,10 @@ namespace cat
                              uint32_t n_limbs, uint32_t n_polys, hipStream_t s);
     cat_status launch_ckks_tensor(cat_ctx *ctx, const u64 *x, const u64 *y, u64 *out, uint32_t L, uint32_t batch,
                                   hipStream_t s);
+    cat_status launch_ckks_square(cat_ctx *ctx, const u64 *x, u64 *out, uint32_t L, uint32_t batch, hipStream_t s);
+    // op: 0 = multiply, 1 = add, 2 = subtract; plain_stride in words (0 = one plaintext for the whole batch)
+    cat_status launch_plain(cat_ctx *ctx, int op, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out,
+                            uint32_t L, uint32_t size, uint32_t batch, hipStream_t s);
     cat_status launch_galois(cat_ctx *ctx, bool ntt_domain, const u64 *in, u64 *out, uint32_t elt, const LimbMap &map,
                              uint32_t n_limbs, uint32_t n_polys, hipStream_t s);
     cat_status launch_drop_limb(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t n_polys, hipStream_t s);

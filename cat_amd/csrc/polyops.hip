@@ -125,6 +125,84 @@ namespace
         }
     }
 
+    // ckks_square (evaluator.cpp:1022-1078), size 2 -> 3: (c0^2, 2 c0 c1, c1^2); 2 reads + 3 writes per coefficient
+    __global__ __launch_bounds__(256) void ckks_square_kernel(TensorArgs g)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u64 ct = i / g.poly2, off = i % g.poly2;
+            const u32 limb = (u32)((off * 2) >> g.log_n);
+            const DevMod m = g.mods[limb];
+            const ulonglong2 *x = reinterpret_cast<const ulonglong2 *>(g.x) + ct * 2 * g.poly2 + off;
+            ulonglong2 *o = reinterpret_cast<ulonglong2 *>(g.out) + ct * 3 * g.poly2 + off;
+            const ulonglong2 x0 = x[0], x1 = x[g.poly2];
+            ulonglong2 r0, r1, r2;
+            r0.x = mul_mod(x0.x, x0.x, m.q, m.ratio0, m.ratio1);
+            r0.y = mul_mod(x0.y, x0.y, m.q, m.ratio0, m.ratio1);
+            r2.x = mul_mod(x1.x, x1.x, m.q, m.ratio0, m.ratio1);
+            r2.y = mul_mod(x1.y, x1.y, m.q, m.ratio0, m.ratio1);
+            r1.x = mul_mod(x0.x, x1.x, m.q, m.ratio0, m.ratio1);
+            r1.y = mul_mod(x0.y, x1.y, m.q, m.ratio0, m.ratio1);
+            r1.x = add_mod(r1.x, r1.x, m.q);
+            r1.y = add_mod(r1.y, r1.y, m.q);
+            o[0] = r0;
+            o[g.poly2] = r1;
+            o[2 * g.poly2] = r2;
+        }
+    }
+
+    // Plaintext operand ops on batch x size x L x N ciphertexts; the plaintext is L x N (stride 0 = shared by the
+    // batch).  MUL: every polynomial times plain (multiply_plain_ntt, evaluator.cpp:2135-2172); ADD / SUB: c0 +- plain,
+    // the other polynomials copied (add_plain / sub_plain, CKKS branch, evaluator.cpp:1737-1951).
+    struct PlainArgs
+    {
+        const u64 *ct;
+        const u64 *plain;
+        u64 *out;
+        const DevMod *mods;
+        u32 L, log_n, size;
+        u64 plain_stride2; // vectors between consecutive plaintexts (0 = one plaintext for the whole batch)
+        u64 total2;        // batch * size * L * N / 2
+    };
+
+    enum PlainOp { PL_MUL, PL_ADD, PL_SUB };
+
+    template <int OP>
+    __global__ __launch_bounds__(256) void plain_kernel(PlainArgs g)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u64 poly2 = ((u64)g.L << g.log_n) >> 1;
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u64 pidx = i / poly2, off = i % poly2;
+            const u64 b = pidx / g.size;
+            const u32 poly = (u32)(pidx % g.size);
+            const DevMod m = g.mods[(off * 2) >> g.log_n];
+            ulonglong2 x = reinterpret_cast<const ulonglong2 *>(g.ct)[i];
+            if (OP == PL_MUL || poly == 0)
+            {
+                const ulonglong2 p = reinterpret_cast<const ulonglong2 *>(g.plain)[b * g.plain_stride2 + off];
+                if (OP == PL_MUL)
+                {
+                    x.x = mul_mod(x.x, p.x, m.q, m.ratio0, m.ratio1);
+                    x.y = mul_mod(x.y, p.y, m.q, m.ratio0, m.ratio1);
+                }
+                else if (OP == PL_ADD)
+                {
+                    x.x = add_mod(x.x, p.x, m.q);
+                    x.y = add_mod(x.y, p.y, m.q);
+                }
+                else
+                {
+                    x.x = sub_mod(x.x, p.x, m.q);
+                    x.y = sub_mod(x.y, p.y, m.q);
+                }
+            }
+            reinterpret_cast<ulonglong2 *>(g.out)[i] = x;
+        }
+    }
+
     // Galois: out[i] = in[bitrev(((elt * bitrev_{logn+1}(N + i)) >> 1) & (N-1))]  (galois.cpp:36-43, 217)
     struct GaloisArgs
     {
@@ -280,6 +358,50 @@ namespace cat
         if (g.total2 == 0)
             return CAT_OK;
         hipLaunchKernelGGL(ckks_tensor_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+        CAT_HIP(hipGetLastError());
+        return CAT_OK;
+    }
+
+    cat_status launch_ckks_square(cat_ctx *ctx, const u64 *x, u64 *out, uint32_t L, uint32_t batch, hipStream_t s)
+    {
+        TensorArgs g;
+        g.x = x;
+        g.y = x;
+        g.out = out;
+        g.mods = ctx->d_mods;
+        g.L = L;
+        g.log_n = ctx->log_n;
+        g.poly2 = ((u64)L << ctx->log_n) >> 1;
+        g.total2 = g.poly2 * batch;
+        if (g.total2 == 0)
+            return CAT_OK;
+        hipLaunchKernelGGL(ckks_square_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+        CAT_HIP(hipGetLastError());
+        return CAT_OK;
+    }
+
+    cat_status launch_plain(cat_ctx *ctx, int op, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out,
+                            uint32_t L, uint32_t size, uint32_t batch, hipStream_t s)
+    {
+        PlainArgs g;
+        g.ct = ct;
+        g.plain = plain;
+        g.out = out;
+        g.mods = ctx->d_mods;
+        g.L = L;
+        g.log_n = ctx->log_n;
+        g.size = size;
+        g.plain_stride2 = plain_stride / 2;
+        g.total2 = (((u64)batch * size * L) << ctx->log_n) >> 1;
+        if (g.total2 == 0)
+            return CAT_OK;
+        const u32 grid = grid_for(g.total2);
+        switch (op)
+        {
+        case PL_MUL: hipLaunchKernelGGL(plain_kernel<PL_MUL>, dim3(grid), dim3(256), 0, s, g); break;
+        case PL_ADD: hipLaunchKernelGGL(plain_kernel<PL_ADD>, dim3(grid), dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL(plain_kernel<PL_SUB>, dim3(grid), dim3(256), 0, s, g); break;
+        }
         CAT_HIP(hipGetLastError());
         return CAT_OK;
     }

@@ -123,6 +123,21 @@ cat_status cat_modulo(cat_ctx *ctx, const uint64_t *d_a, uint64_t *d_out, const 
 cat_status cat_ckks_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, uint64_t *d_out, uint32_t L,
                              uint32_t batch, cat_stream s);
 
+/* ---- f1 ("next" row 1): squares and plaintext operands, same layout and kernels' arithmetic -------
+ * Evaluator::ckks_square, size 2 -> 3 (evaluator.cpp:1022-1078): (c0^2, 2 c0 c1, c1^2); d_out must not alias d_x. */
+cat_status cat_ckks_square(cat_ctx *ctx, const uint64_t *d_x, uint64_t *d_out, uint32_t L, uint32_t batch, cat_stream s);
+/* Evaluator::multiply_plain_ntt (evaluator.cpp:2135-2172): every polynomial of each ciphertext times the NTT-form
+ * plaintext.  d_ct, d_out: batch x size x L x N (may alias); d_plain: L x N words per plaintext, plain_stride words
+ * apart (0 = one plaintext shared by the batch).  The scale bookkeeping stays with the caller. */
+cat_status cat_multiply_plain_ntt(cat_ctx *ctx, const uint64_t *d_ct, const uint64_t *d_plain, size_t plain_stride,
+                                  uint64_t *d_out, uint32_t L, uint32_t size, uint32_t batch, cat_stream s);
+/* Evaluator::add_plain_inplace / sub_plain_inplace, CKKS branch (evaluator.cpp:1737-1951): c0 +- plain, both in NTT
+ * form at the same level and scale; the other polynomials are copied when d_out != d_ct. */
+cat_status cat_add_plain(cat_ctx *ctx, const uint64_t *d_ct, const uint64_t *d_plain, size_t plain_stride,
+                         uint64_t *d_out, uint32_t L, uint32_t size, uint32_t batch, cat_stream s);
+cat_status cat_sub_plain(cat_ctx *ctx, const uint64_t *d_ct, const uint64_t *d_plain, size_t plain_stride,
+                         uint64_t *d_out, uint32_t L, uint32_t size, uint32_t batch, cat_stream s);
+
 /* ---- a8: Evaluator::switch_key_inplace (evaluator.cpp:2523-2820), CKKS and BFV branches ------------
  * d_encrypted: batch x 2 x L x N, updated in place (encrypted[comp][j] += mod-down result).
  * d_target:    batch x L x N (NTT form for CKKS, coefficient form for BFV); must not alias d_encrypted.

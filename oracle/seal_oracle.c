@@ -1232,6 +1232,43 @@ void so_ckks_multiply(const so_context *c, size_t L, uint64_t *x, const uint64_t
     free(temp);
 }
 
+/* evaluator.cpp:1022-1078 (size 2 -> 3): x has room for 3 polys */
+void so_ckks_square(const so_context *c, size_t L, uint64_t *x)
+{
+    size_t n = c->n;
+    for (size_t i = 0; i < L; i++)
+    {
+        const so_modulus *m = &c->mod[i];
+        uint64_t *x0 = x + i * n, *x1 = x + (L + i) * n, *x2 = x + (2 * L + i) * n;
+        so_dyadic_product_coeffmod(x1, x1, n, m, x2);
+        so_dyadic_product_coeffmod(x0, x1, n, m, x1);
+        so_add_poly_coeffmod(x1, x1, n, m, x1);
+        so_dyadic_product_coeffmod(x0, x0, n, m, x0);
+    }
+}
+
+/* evaluator.cpp:2135-2172: every polynomial of the ciphertext times the NTT-form plaintext (L limbs) */
+void so_multiply_plain_ntt(const so_context *c, size_t L, uint64_t *ct, size_t size, const uint64_t *plain)
+{
+    size_t n = c->n;
+    for (size_t p = 0; p < size; p++)
+        for (size_t i = 0; i < L; i++)
+            so_dyadic_product_coeffmod(ct + (p * L + i) * n, plain + i * n, n, &c->mod[i], ct + (p * L + i) * n);
+}
+
+/* evaluator.cpp:1737-1843 / 1845-1951, CKKS branch (:1812-1817, :1920-1925): c0 +- plain */
+void so_add_plain_ckks(const so_context *c, size_t L, uint64_t *ct, const uint64_t *plain, int subtract)
+{
+    size_t n = c->n;
+    for (size_t i = 0; i < L; i++)
+    {
+        if (subtract)
+            so_sub_poly_coeffmod(ct + i * n, plain + i * n, n, &c->mod[i], ct + i * n);
+        else
+            so_add_poly_coeffmod(ct + i * n, plain + i * n, n, &c->mod[i], ct + i * n);
+    }
+}
+
 /* evaluator.cpp:664-700 */
 void so_ckks_multiply_general(const so_context *c, size_t L, uint64_t *x, size_t xs, const uint64_t *y, size_t ys)
 {

@@ -129,6 +129,10 @@ const so_rnstool *so_context_rnstool(so_context *c, size_t L);
 void so_ckks_multiply(const so_context *c, size_t L, uint64_t *x, const uint64_t *y);
 /* general sizes, evaluator.cpp:664-700; x must have room for (xs+ys-1) polys */
 void so_ckks_multiply_general(const so_context *c, size_t L, uint64_t *x, size_t xs, const uint64_t *y, size_t ys);
+/* evaluator.cpp:1022-1078, 2135-2172, 1737-1951 (CKKS branch) */
+void so_ckks_square(const so_context *c, size_t L, uint64_t *x);
+void so_multiply_plain_ntt(const so_context *c, size_t L, uint64_t *ct, size_t size, const uint64_t *plain);
+void so_add_plain_ckks(const so_context *c, size_t L, uint64_t *ct, const uint64_t *plain, int subtract);
 /* evaluator.cpp:395-567 (sizes 2x2 -> 3, coefficient form) */
 void so_bfv_multiply(so_context *c, size_t L, uint64_t *x, const uint64_t *y);
 /* evaluator.cpp:2523-2820; encrypted: 2 polys x L limbs; target: L limbs;

@@ -109,6 +109,9 @@ def lib() -> C.CDLL:
             "so_ckks_multiply": (None, [vp, sz, u64p, u64p]),
             "so_ckks_multiply_general": (None, [vp, sz, u64p, sz, u64p, sz]),
             "so_bfv_multiply": (None, [vp, sz, u64p, u64p]),
+            "so_ckks_square": (None, [vp, sz, u64p]),
+            "so_multiply_plain_ntt": (None, [vp, sz, u64p, sz, u64p]),
+            "so_add_plain_ckks": (None, [vp, sz, u64p, u64p, C.c_int]),
             "so_switch_key_inplace": (None, [vp, sz, u64p, u64p, u64p]),
             "so_relinearize": (None, [vp, sz, u64p, u64p]),
             "so_mod_switch_scale_to_next": (None, [vp, sz, u64p, sz, u64p]),
@@ -318,6 +321,23 @@ class Context:
         y = arr(y)
         lib().so_ckks_multiply_general(self.h, L, ptr(out), xs, ptr(y), ys)
         return out
+
+    def ckks_square(self, x: np.ndarray) -> np.ndarray:
+        L = x.shape[1]
+        out = np.zeros((3, L, self.n), dtype=np.uint64)
+        out[:2] = x
+        lib().so_ckks_square(self.h, L, ptr(out))
+        return out
+
+    def multiply_plain_ntt(self, ct: np.ndarray, plain: np.ndarray) -> np.ndarray:
+        ct, plain = arr(ct).copy(), arr(plain)
+        lib().so_multiply_plain_ntt(self.h, ct.shape[1], ptr(ct), ct.shape[0], ptr(plain))
+        return ct
+
+    def add_plain(self, ct: np.ndarray, plain: np.ndarray, subtract=False) -> np.ndarray:
+        ct, plain = arr(ct).copy(), arr(plain)
+        lib().so_add_plain_ckks(self.h, ct.shape[1], ptr(ct), ptr(plain), int(subtract))
+        return ct
 
     def bfv_multiply(self, x: np.ndarray, y: np.ndarray) -> np.ndarray:
         L = x.shape[1]

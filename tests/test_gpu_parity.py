@@ -407,3 +407,36 @@ def test_bfv_config3_multiply_relinearize(cat, oracle):
     relin = host(ctx.relinearize(got, dev(rk)).contiguous())
     assert (relin[0] == octx.relinearize(exp, rk)).all()
     ctx.close()
+
+
+def test_square_and_plaintext_operands(cat, oracle):
+    """ckks_square, multiply_plain_ntt, add_plain / sub_plain on the device vs the oracle."""
+    log_n = 12
+    n = 1 << log_n
+    primes = oracle.coeff_modulus_create(n, [60, 40, 40, 60])
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_CKKS)
+    batch, L = 3, 3
+    x = np.stack([octx.uniform(L, 2, 90 + b) for b in range(batch)])
+    x3 = np.stack([octx.uniform(L, 3, 95 + b) for b in range(batch)])
+    plains = np.stack([octx.uniform(L, 1, 99 + b)[0] for b in range(batch)])
+    assert (host(ctx.ckks_square(dev(x))) == np.stack([octx.ckks_square(x[b]) for b in range(batch)])).all()
+    # one plaintext per ciphertext, and one shared by the batch; size 2 and size 3
+    got = host(ctx.multiply_plain_ntt(dev(x3), dev(plains)))
+    assert (got == np.stack([octx.multiply_plain_ntt(x3[b], plains[b]) for b in range(batch)])).all()
+    got = host(ctx.multiply_plain_ntt(dev(x), dev(plains[0])))
+    assert (got == np.stack([octx.multiply_plain_ntt(x[b], plains[0]) for b in range(batch)])).all()
+    dx = dev(x3)
+    ctx.multiply_plain_ntt(dx, dev(plains), out=dx)  # in place
+    assert (host(dx) == np.stack([octx.multiply_plain_ntt(x3[b], plains[b]) for b in range(batch)])).all()
+    got = host(ctx.add_plain(dev(x3), dev(plains)))
+    assert (got == np.stack([octx.add_plain(x3[b], plains[b]) for b in range(batch)])).all()
+    got = host(ctx.sub_plain(dev(x), dev(plains[1])))
+    assert (got == np.stack([octx.add_plain(x[b], plains[1], subtract=True) for b in range(batch)])).all()
+    import torch
+
+    big = torch.zeros((batch, 3, L, n), dtype=torch.int64, device="cuda")
+    alias = big.view(-1)[: batch * 2 * L * n].view(batch, 2, L, n)
+    with pytest.raises(ValueError):
+        ctx.ckks_square(alias, out=big)  # destination must not alias the input
+    ctx.close()

@@ -162,3 +162,23 @@ def test_ntt_convolution_theorem(oracle):
     assert (lz < 4 * q).all() and ((lz % q) == fa).all()
     li = t.inverse(fa, lazy=True)
     assert (li < 2 * q).all() and ((li % q) == np.array(a, dtype=np.uint64)).all()
+
+
+def test_square_and_plain_ops_are_consistent(oracle):
+    """ckks_square (evaluator.cpp:1022-1078) equals ckks_multiply(x, x); multiply_plain_ntt is the dyadic product
+    per polynomial; add_plain then sub_plain is the identity."""
+    n, log_n = 1024, 10
+    primes = oracle.coeff_modulus_create(n, [40, 30, 30, 40])
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    x = octx.uniform(3, 2, 5)
+    assert (octx.ckks_square(x) == octx.ckks_multiply(x, x)).all()
+    plain = octx.uniform(3, 1, 6)[0]
+    prod = octx.multiply_plain_ntt(x, plain)
+    qs = [int(p) for p in primes[:3]]
+    for p in range(2):
+        for j in range(3):
+            exp = [(int(a) * int(b)) % qs[j] for a, b in zip(x[p, j, :8], plain[j, :8])]
+            assert prod[p, j, :8].tolist() == exp
+    s = octx.add_plain(x, plain)
+    assert (s[1] == x[1]).all() and not (s[0] == x[0]).all()
+    assert (octx.add_plain(s, plain, subtract=True) == x).all()
