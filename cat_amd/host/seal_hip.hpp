@@ -7,8 +7,9 @@
 //   seal::util::{add,sub,negate}_poly_coeffmod, dyadic_product_coeffmod               util/polyarithsmallmod.cuh:84-611
 //   seal::Ciphertext (size/coeff_modulus_size/is_ntt_form/scale, to_gpu/to_cpu)        ciphertext.cuh:356-385, 496-735
 //   seal::KSwitchKeys / RelinKeys / GaloisKeys (get_index, has_key)                   kswitchkeys.h:36-131, relinkeys.h:58-64, galoiskeys.h:48-50
-//   seal::Evaluator::{add,sub,negate,multiply,relinearize,rescale_to_next,mod_switch_to_next,
-//                     transform_{to,from}_ntt,apply_galois,rotate_vector,rotate_rows,complex_conjugate}_inplace
+//   seal::Evaluator::{add,sub,negate,multiply,square,multiply_plain,add_plain,sub_plain,relinearize,rescale_to_next,
+//                     mod_switch_to_next,transform_{to,from}_ntt,apply_galois,rotate_vector,rotate_rows,
+//                     complex_conjugate}_inplace
 //                                                                                      evaluator.h:88-1298
 // Differences that are deliberate: data lives on the device (the reference keeps a host array plus a
 // device shadow; here upload()/download() are the to_gpu()/to_cpu() of ciphertext.cuh:361-381); key
@@ -18,6 +19,7 @@
 
 #include "../../include/cat_amd.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <memory>
@@ -347,6 +349,51 @@ namespace seal
         double scale_ = 1.0;
     };
 
+    // Device-resident NTT-form CKKS plaintext: coeff_modulus_size x N words (plaintext.h; produced by CKKSEncoder on
+    // the host, which stays with the caller).
+    class Plaintext
+    {
+    public:
+        Plaintext(const SEALContext &context, std::size_t coeff_modulus_size) : buf_(context, coeff_modulus_size, 2)
+        {
+            // storage is borrowed from Ciphertext (2 polys allocated, the first one used)
+            buf_.is_ntt_form() = true;
+        }
+        void upload(const std::uint64_t *host)
+        {
+            std::vector<std::uint64_t> tmp(buf_.words(), 0);
+            std::copy(host, host + buf_.words() / 2, tmp.begin());
+            buf_.upload(tmp.data());
+        }
+        const std::uint64_t *d_data() const noexcept
+        {
+            return buf_.d_data();
+        }
+        std::size_t coeff_modulus_size() const noexcept
+        {
+            return buf_.coeff_modulus_size();
+        }
+        bool is_ntt_form() const noexcept
+        {
+            return buf_.is_ntt_form();
+        }
+        bool &is_ntt_form() noexcept
+        {
+            return buf_.is_ntt_form();
+        }
+        double scale() const noexcept
+        {
+            return buf_.scale();
+        }
+        double &scale() noexcept
+        {
+            return buf_.scale();
+        }
+
+    private:
+        Ciphertext buf_;
+    };
+
     // KSwitchKeys::data()[index] = vector<PublicKey>, one PublicKey per decomposition prime, each 2 x k x N
     // words in NTT form (kswitchkeys.h:90-101).  Here every index holds one device array [k-1][2][k][N].
     class KSwitchKeys
@@ -595,6 +642,52 @@ namespace seal
             multiply_inplace(destination, encrypted2);
         }
 
+        // evaluator.cpp:993-1078 (CKKS, size 2 -> 3)
+        void square_inplace(Ciphertext &encrypted) const
+        {
+            verify(encrypted, "encrypted");
+            if (context_.parms().scheme() != scheme_type::ckks)
+            {
+                Ciphertext copy(encrypted);
+                multiply_inplace(encrypted, copy);
+                return;
+            }
+            if (!encrypted.is_ntt_form())
+                throw std::invalid_argument("encrypted must be in NTT form");
+            if (encrypted.size() != 2)
+                throw std::logic_error("unsupported: only size-2 operands are squared on the device");
+            const std::uint32_t L = (std::uint32_t)encrypted.coeff_modulus_size();
+            Ciphertext dest(context_, L, 3);
+            detail::check(cat_ckks_square(h(), encrypted.d_data(), dest.d_data(), L, 1, nullptr));
+            dest.is_ntt_form() = true;
+            dest.scale() = encrypted.scale() * encrypted.scale();
+            encrypted = std::move(dest);
+        }
+
+        // evaluator.cpp:1953-1983 -> multiply_plain_ntt :2135-2172
+        void multiply_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const
+        {
+            verify(encrypted, "encrypted");
+            if (!encrypted.is_ntt_form() || !plain.is_ntt_form())
+                throw std::invalid_argument(encrypted.is_ntt_form() ? "plain_ntt is not in NTT form" : "NTT form mismatch");
+            if (encrypted.coeff_modulus_size() != plain.coeff_modulus_size())
+                throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
+            detail::check(cat_multiply_plain_ntt(h(), encrypted.d_data(), plain.d_data(), 0, encrypted.d_data(),
+                                                 (std::uint32_t)encrypted.coeff_modulus_size(),
+                                                 (std::uint32_t)encrypted.size(), 1, nullptr));
+            encrypted.scale() *= plain.scale();
+        }
+
+        // evaluator.cpp:1737-1843 / 1845-1951, CKKS branch
+        void add_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const
+        {
+            plain_addsub(encrypted, plain, false);
+        }
+        void sub_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const
+        {
+            plain_addsub(encrypted, plain, true);
+        }
+
         // evaluator.cpp:1144-1199 (destination_size 2): one key switch per dropped polynomial
         void relinearize_inplace(Ciphertext &encrypted, const RelinKeys &relin_keys) const
         {
@@ -744,6 +837,21 @@ namespace seal
                 throw std::invalid_argument("NTT form mismatch");
             if (a.scale() != b.scale())
                 throw std::invalid_argument("scale mismatch");
+        }
+        void plain_addsub(Ciphertext &encrypted, const Plaintext &plain, bool sub) const
+        {
+            verify(encrypted, "encrypted");
+            if (context_.parms().scheme() != scheme_type::ckks)
+                throw std::logic_error("unsupported: plaintext add/sub on the device is the CKKS branch only");
+            if (!encrypted.is_ntt_form() || !plain.is_ntt_form())
+                throw std::invalid_argument("NTT form mismatch");
+            if (encrypted.coeff_modulus_size() != plain.coeff_modulus_size())
+                throw std::invalid_argument("encrypted and plain parameter mismatch");
+            if (encrypted.scale() != plain.scale())
+                throw std::invalid_argument("scale mismatch");
+            auto fn = sub ? cat_sub_plain : cat_add_plain;
+            detail::check(fn(h(), encrypted.d_data(), plain.d_data(), 0, encrypted.d_data(),
+                             (std::uint32_t)encrypted.coeff_modulus_size(), (std::uint32_t)encrypted.size(), 1, nullptr));
         }
         // mod_switch_scale_to_next (evaluator.cpp:1201-1280)
         void scale_to_next(const Ciphertext &encrypted, Ciphertext &destination) const

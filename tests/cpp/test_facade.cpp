@@ -133,6 +133,34 @@ static void test_ckks()
         EXPECT(s.to_cpu() == x);
     }
 
+    // square, multiply_plain, add_plain / sub_plain (tests/evaluator.cpp:3354-3538 drive the same calls)
+    {
+        Ciphertext s(encrypted1);
+        vec e(3 * L * n, 0);
+        std::memcpy(e.data(), x.data(), x.size() * 8);
+        so_ckks_square(oc, L, e.data());
+        evaluator.square_inplace(s);
+        EXPECT(s.size() == 3 && s.to_cpu() == e && s.scale() == delta * delta);
+        vec pl = uniform(oc, L, 1, n, 12);
+        Plaintext plain(context, L);
+        plain.upload(pl.data());
+        plain.scale() = delta;
+        Ciphertext m(encrypted1);
+        vec em = x;
+        so_multiply_plain_ntt(oc, L, em.data(), 2, pl.data());
+        evaluator.multiply_plain_inplace(m, plain);
+        EXPECT(m.to_cpu() == em && m.scale() == delta * delta);
+        Ciphertext a(encrypted1);
+        vec ea = x;
+        so_add_plain_ckks(oc, L, ea.data(), pl.data(), 0);
+        evaluator.add_plain_inplace(a, plain);
+        EXPECT(a.to_cpu() == ea);
+        evaluator.sub_plain_inplace(a, plain);
+        EXPECT(a.to_cpu() == x);
+        plain.scale() = 2 * delta;
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.add_plain_inplace(a, plain); })); // scale mismatch
+    }
+
     // multiply -> relinearize -> rescale (tests/evaluator.cpp:3539-3623)
     vec exp3(3 * L * n, 0);
     std::memcpy(exp3.data(), x.data(), x.size() * 8);
