@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Throughput of the BASELINE.json configurations that are not bench.py's headline line (configs 3, 4, 5), one GPU,
+inputs resident in HBM, each result first checked against the CPU oracle on one batch element.
+Usage: python3 tools/bench_configs.py [--steps K]   -> one JSON object per line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import cat_amd
+from cat_amd.api import to_device, to_host
+from oracle import seal_oracle as so
+
+
+def timed(fn, steps, warmup=1):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def uniform(primes, prefix, n, gen):
+    out = torch.empty(tuple(prefix) + (len(primes), n), dtype=torch.int64, device="cuda")
+    for j, q in enumerate(primes):
+        out[..., j, :] = torch.randint(0, q, tuple(prefix) + (n,), dtype=torch.int64, device="cuda", generator=gen)
+    return out
+
+
+def config3(steps):
+    log_n, n, t = 14, 16384, 786433
+    primes = so.bfv_default(n)
+    octx = so.Context(log_n, primes, so.SCHEME_BFV, t)
+    ctx = cat_amd.Context(log_n, primes, cat_amd.SCHEME_BFV, t)
+    L, B = 8, 64
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    x, y = uniform(primes[:L], (B, 2), n, gen), uniform(primes[:L], (B, 2), n, gen)
+    rk = octx.relin_key(octx.secret_key(1), 2)
+    drk = to_device(rk)
+    out = torch.empty((B, 3, L, n), dtype=torch.int64, device="cuda")
+
+    def step():
+        ctx.bfv_multiply(x, y, out=out)
+        ctx.relinearize(out, drk)
+
+    step()
+    exp = octx.relinearize(octx.bfv_multiply(to_host(x[0]), to_host(y[0])), rk)
+    ok = bool((to_host(out[0, :2]) == exp).all())
+    dt = timed(step, steps)
+    return {"config": 3, "workload": f"BFV N=16384, 9-prime BFVDefault (438 bit), multiply_inplace + relinearize_inplace, batch {B}",
+            "ops_per_s": B / dt, "ms_per_step": dt * 1e3, "parity_checked": ok}
+
+
+def config4(steps):
+    log_n, n = 16, 65536
+    primes = list(reversed(so.get_primes(2 * n, 60, 25)))
+    octx = so.Context(log_n, primes, so.SCHEME_CKKS)
+    ctx = cat_amd.Context(log_n, primes, cat_amd.SCHEME_CKKS)
+    B, L = 8, 24
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4)
+    ct0 = uniform(primes[:L], (B, 2), n, gen)
+    gk = octx.galois_key(octx.secret_key(1), 3, 2)
+    dgk = to_device(gk)
+    levels = 4
+
+    def chain():
+        cur = ct0.clone()
+        for _ in range(levels):
+            ctx.rotate_vector(cur, 1, dgk)
+            cur = ctx.rescale(cur)
+        return cur
+
+    got = chain()
+    e = to_host(ct0[0])
+    for _ in range(levels):
+        e = octx.rescale(octx.apply_galois_inplace(e, 3, gk))
+    ok = bool((to_host(got[0]) == e).all())
+    dt = timed(chain, steps)
+    return {"config": 4, "workload": f"CKKS N=65536, 24+1 60-bit primes, (rotate_vector(1) + rescale_to_next) x {levels} levels from L=24, batch {B}",
+            "rotate_rescale_pairs_per_s": B * levels / dt, "ms_per_chain": dt * 1e3, "parity_checked": ok}
+
+
+def config5(steps):
+    log_n, n = 15, 32768
+    primes = so.bfv_default(n)
+    octx = so.Context(log_n, primes, so.SCHEME_CKKS)
+    ctx = cat_amd.Context(log_n, primes, cat_amd.SCHEME_CKKS)
+    L, B = 15, 64  # 1024 pairs per GPU are processed as 16 such slices
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    x, y = uniform(primes[:L], (B, 2), n, gen), uniform(primes[:L], (B, 2), n, gen)
+    rk = octx.relin_key(octx.secret_key(1), 2)
+    drk = to_device(rk)
+    out = torch.empty((B, 3, L, n), dtype=torch.int64, device="cuda")
+
+    def step():
+        ctx.ckks_multiply(x, y, out=out)
+        ctx.relinearize(out, drk)
+
+    step()
+    exp = octx.relinearize(octx.ckks_multiply(to_host(x[0]), to_host(y[0])), rk)
+    ok = bool((to_host(out[0, :2]) == exp).all())
+    dt = timed(step, steps)
+    return {"config": 5, "workload": f"CKKS N=32768, 16-prime BFVDefault (15 + special), multiply + relinearize, slices of {B} pairs (one GPU's share of the 8192-pair batch is 1024 pairs)",
+            "ops_per_s": B / dt, "ms_per_slice": dt * 1e3, "s_per_1024_pairs": 1024 / (B / dt), "parity_checked": ok}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    a = ap.parse_args()
+    for f in (config3, config4, config5):
+        print(json.dumps(f(a.steps)), flush=True)
+        torch.cuda.empty_cache()
