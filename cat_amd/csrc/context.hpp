@@ -90,11 +90,34 @@ namespace cat
     // and fully reduced transforms use the faster split-Shoup arithmetic (same values modulo q, same ranges).
     cat_status launch_ntt(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
                           uint32_t n_polys, bool lazy, hipStream_t s, bool exact = false);
+    // Work fused into a forward transform (key switching and rescale, keyswitch.hip):
+    //  - source of the first pass: instead of the data itself, limb values derived from another buffer
+    //      kind 0 "raise"  (evaluator.cpp:2643-2651): limb j of object p reads limb (j % limb_group) of object p of
+    //                       src, canonical modulo that limb's prime, reduced modulo prime of j when that is smaller;
+    //      kind 1 "round"  (evaluator.cpp:2766-2789, util/rns.cpp:857-878): every limb of object p reads the single
+    //                       polynomial src + p * src_stride holding values < 2Q (Q = prime src_qidx) and forms
+    //                       ((v + Q/2) mod Q) mod q_j + (q_j - (Q/2 mod q_j));
+    //  - epilogue of the last pass (evaluator.cpp:2810-2816, util/rns.cpp:879-899): the transformed limb t (< 4q) is
+    //      not stored; dest = (other + 4q - t) * Q^-1 mod q  [+ dest when ep_acc], with object p = b * ep_S + s
+    //      addressed as base + b * *_b + s * *_s + limb * N.
+    struct NttFuse
+    {
+        const u64 *src = nullptr;
+        u64 src_stride = 0;
+        int src_kind = 0;
+        uint32_t src_qidx = 0;
+        const u64 *ep_other = nullptr;
+        u64 *ep_dest = nullptr;
+        u64 ep_other_b = 0, ep_other_s = 0, ep_dest_b = 0, ep_dest_s = 0;
+        uint32_t ep_S = 1;
+        int ep_acc = 0;
+        uint32_t ep_qidx = 0;
+    };
     // general form: objects `poly_stride` words apart; limb j uses modulus map.id[j / limb_group];
     // skip_diag skips limbs with j % limb_group == j / limb_group (key switching's I == J operands)
     cat_status launch_ntt_ex(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
                              uint32_t n_polys, bool lazy, u64 poly_stride, uint32_t limb_group, bool skip_diag,
-                             hipStream_t s, bool exact = false, const u64 *raise_src = nullptr, u64 raise_src_stride = 0);
+                             hipStream_t s, bool exact = false, const NttFuse *fuse = nullptr);
     cat_status launch_ew(cat_ctx *ctx, int op, const u64 *a, const u64 *b, u64 *out, const LimbMap &map,
                          uint32_t n_limbs, uint32_t n_polys, hipStream_t s);
     cat_status launch_scalar(cat_ctx *ctx, int op, const u64 *a, const u64 *scalars, u64 *out, const LimbMap &map,

@@ -324,8 +324,11 @@ namespace cat
             LimbMap map{};
             for (u32 I = 0; I < rns; ++I)
                 map.id[I] = (unsigned char)(I == d ? k - 1 : I);
+            NttFuse raise;
+            raise.src = coeff_target;
+            raise.src_stride = ckks ? (u64)d * N : (u64)target_stride;
             cat_status st = launch_ntt_ex(ctx, true, ext, map, rns * d, batch, true, (u64)rns * d * N, d, ckks, s, false,
-                                          coeff_target, ckks ? (u64)d * N : (u64)target_stride);
+                                          &raise);
             if (st != CAT_OK)
                 return st;
         }
@@ -369,6 +372,25 @@ namespace cat
             g.lazy_shift = ckks ? 2 : 1;
             g.enc_stride2 = enc_stride / 2;
             g.total2 = w_tmp / 2;
+            if (ckks && log_n >= 12)
+            {
+                // prepare and finish fused into the two passes of the forward transform of tmp (NttFuse)
+                NttFuse f;
+                f.src = prod + (size_t)d * N;
+                f.src_stride = (u64)rns * N;
+                f.src_kind = 1;
+                f.src_qidx = k - 1;
+                f.ep_other = prod;
+                f.ep_other_b = (u64)2 * rns * N;
+                f.ep_other_s = (u64)rns * N;
+                f.ep_dest = enc;
+                f.ep_dest_b = enc_stride;
+                f.ep_dest_s = (u64)d * N;
+                f.ep_S = 2;
+                f.ep_acc = 1;
+                f.ep_qidx = k - 1;
+                return launch_ntt_ex(ctx, true, tmp, ident, d, batch * 2, true, (u64)d * N, 1, false, s, false, &f);
+            }
             hipLaunchKernelGGL(ks_down_prepare_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
             CAT_HIP(hipGetLastError());
             if (ckks)
@@ -426,6 +448,32 @@ namespace cat
             cat_status st = launch_ntt(ctx, false, last, ml, 1, (uint32_t)polys, false, s);
             if (st != CAT_OK)
                 return st;
+            if (ctx->log_n >= 12)
+            {
+                NttFuse f;
+                f.src = last;
+                f.src_stride = N;
+                f.src_kind = 1;
+                f.src_qidx = L - 1;
+                f.ep_other = in;
+                f.ep_other_b = in_stride;
+                f.ep_other_s = (u64)L * N;
+                f.ep_dest = g.out;
+                f.ep_dest_b = g.out_stride2 * 2;
+                f.ep_dest_s = (u64)(L - 1) * N;
+                f.ep_S = size;
+                f.ep_acc = 0;
+                f.ep_qidx = L - 1;
+                st = launch_ntt_ex(ctx, true, tmp, ctx->identity_map(), L - 1, (uint32_t)polys, true, (u64)(L - 1) * N, 1,
+                                   false, s, false, &f);
+                if (st != CAT_OK)
+                    return st;
+                if (alias)
+                    CAT_HIP(hipMemcpy2DAsync(out, out_stride * sizeof(u64), stage,
+                                             (size_t)size * (L - 1) * N * sizeof(u64),
+                                             (size_t)size * (L - 1) * N * sizeof(u64), batch, hipMemcpyDeviceToDevice, s));
+                return CAT_OK;
+            }
             hipLaunchKernelGGL(rescale_prepare_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
             CAT_HIP(hipGetLastError());
             st = launch_ntt(ctx, true, tmp, ctx->identity_map(), L - 1, (uint32_t)polys, true, s);

@@ -52,6 +52,16 @@ namespace
         // transformed limb to data as usual
         const u64 *src;
         u64 src_stride; // words between consecutive src objects
+        u32 src_kind;   // 0 raise, 1 round-and-fix (context.hpp NttFuse)
+        u32 src_qidx;
+        // fused epilogue of the rows pass (NttFuse): active when ep_dest != nullptr
+        const u64 *ep_other;
+        u64 *ep_dest;
+        u64 ep_other_b, ep_other_s, ep_dest_b, ep_dest_s;
+        u32 ep_S, ep_acc, ep_qidx;
+        const u64 *half_mod;  // [kdim][kdim]: (q_a >> 1) mod q_b
+        const MulOp *inv_mod; // [kdim][kdim]: q_a^-1 mod q_b
+        u32 kdim;
     };
 
     struct Where
@@ -62,6 +72,7 @@ namespace
         bool skip;
         u64 src_offset; // fused raise: word offset of the source limb and its prime
         u32 src_mod;
+        u32 poly, limb;
     };
 
     // limb is the slowest index so that concurrently running workgroups share one prime's twiddles in L2
@@ -75,6 +86,8 @@ namespace
         w.mod = a.map.id[grp];
         w.skip = a.skip_diag && (limb - grp * a.limb_group == grp);
         w.offset = (u64)poly * a.poly_stride + ((u64)limb << a.log_n);
+        w.poly = poly;
+        w.limb = limb;
         w.src_mod = limb - grp * a.limb_group;
         w.src_offset = (u64)poly * a.src_stride + ((u64)w.src_mod << a.log_n);
         return w;
@@ -98,36 +111,60 @@ namespace
         return x >= K ? t : x;
     }
 
-    // Input side of a forward first pass: the data itself, or (fused raise) the source limb reduced modulo q.
+    // Input side of a forward first pass: the data itself, or values derived from another buffer (NttFuse).
     struct Source
     {
         const u64 *p;
-        u64 q, ratio1;
-        bool reduce;
+        u64 q, ratio1;   // the limb's own prime
+        u64 Q, Qratio1;  // kind 1: prime of the source values
+        u64 half, fix;
+        int mode;        // 0 plain, 1 reduce modulo q, 2 round-and-fix
+        bool reduce2;
         __device__ __forceinline__ u64 operator()(u32 i) const
         {
-            const u64 v = p[i];
-            return reduce ? barrett64(v, q, ratio1) : v;
+            u64 v = p[i];
+            if (mode == 1)
+                v = barrett64(v, q, ratio1);
+            else if (mode == 2)
+            {
+                v = barrett64(v + half, Q, Qratio1);
+                if (reduce2)
+                    v = barrett64(v, q, ratio1);
+                v += fix;
+            }
+            return v;
         }
     };
 
     __device__ __forceinline__ Source source(const NttArgs &a, const Where &w, u64 extra)
     {
         Source s;
-        if (a.src)
+        s.q = s.ratio1 = s.Q = s.Qratio1 = s.half = s.fix = 0;
+        s.reduce2 = false;
+        if (!a.src)
         {
-            const NttMod m = a.mods[w.mod];
+            s.p = a.data + w.offset + extra;
+            s.mode = 0;
+            return s;
+        }
+        const NttMod m = a.mods[w.mod];
+        s.q = m.q;
+        s.ratio1 = m.ratio1;
+        if (a.src_kind == 0)
+        {
             s.p = a.src + w.src_offset + extra;
-            s.q = m.q;
-            s.ratio1 = m.ratio1;
-            s.reduce = a.mods[w.src_mod].q > m.q; // copy when q_J <= q_I (evaluator.cpp:2643)
+            s.mode = a.mods[w.src_mod].q > m.q ? 1 : 0; // copy when q_J <= q_I (evaluator.cpp:2643)
         }
         else
         {
-            s.p = a.data + w.offset + extra;
-            s.q = 0;
-            s.ratio1 = 0;
-            s.reduce = false;
+            const NttMod Q = a.mods[a.src_qidx];
+            s.p = a.src + (u64)w.poly * a.src_stride + extra;
+            s.Q = Q.q;
+            s.Qratio1 = Q.ratio1;
+            s.half = Q.q >> 1;
+            s.fix = m.q - a.half_mod[a.src_qidx * a.kdim + w.mod];
+            s.reduce2 = Q.q > m.q;
+            s.mode = 2;
         }
         return s;
     }
@@ -427,6 +464,24 @@ namespace
         for (int l = 0; l < 16; ++l)
             s[t * 17 + l] = x[l];
         wave_lds_sync();
+        if (a.ep_dest)
+        {
+            const u32 b = w.poly / a.ep_S, si = w.poly - b * a.ep_S;
+            const u64 in_limb = ((u64)w.limb << a.log_n) + (size_t)row * ROW_LEN;
+            const u64 *other = a.ep_other + b * a.ep_other_b + si * a.ep_other_s + in_limb;
+            u64 *dest = a.ep_dest + b * a.ep_dest_b + si * a.ep_dest_s + in_limb;
+            const MulOp inv = a.inv_mod[a.ep_qidx * a.kdim + w.mod];
+            const u64 q4 = m.q << 2;
+#pragma unroll
+            for (int h = 0; h < 16; ++h)
+            {
+                u64 v = mul_shoup(other[h * 16 + t] + q4 - s[h * 17 + t], inv.op, inv.quo, m.q);
+                if (a.ep_acc)
+                    v = add_mod(v, dest[h * 16 + t], m.q);
+                dest[h * 16 + t] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 16; ++h)
             p[h * 16 + t] = s[h * 17 + t];
@@ -685,12 +740,12 @@ namespace cat
                           uint32_t n_polys, bool lazy, hipStream_t s, bool exact)
     {
         return launch_ntt_ex(ctx, forward, d_data, map, n_limbs, n_polys, lazy, (u64)n_limbs << ctx->log_n, 1, false,
-                             s, exact, nullptr, 0);
+                             s, exact, nullptr);
     }
 
     cat_status launch_ntt_ex(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
                              uint32_t n_polys, bool lazy, u64 poly_stride, uint32_t limb_group, bool skip_diag,
-                             hipStream_t s, bool exact, const u64 *raise_src, u64 raise_src_stride)
+                             hipStream_t s, bool exact, const NttFuse *fuse)
     {
         if (n_limbs == 0 || n_polys == 0)
             return CAT_OK;
@@ -705,8 +760,35 @@ namespace cat
         a.poly_stride = poly_stride;
         a.limb_group = limb_group;
         a.skip_diag = skip_diag ? 1 : 0;
-        a.src = forward ? raise_src : nullptr;
-        a.src_stride = raise_src_stride;
+        a.src = nullptr;
+        a.src_stride = 0;
+        a.src_kind = a.src_qidx = 0;
+        a.ep_other = nullptr;
+        a.ep_dest = nullptr;
+        a.ep_other_b = a.ep_other_s = a.ep_dest_b = a.ep_dest_s = 0;
+        a.ep_S = 1;
+        a.ep_acc = a.ep_qidx = 0;
+        a.half_mod = ctx->d_half_mod;
+        a.inv_mod = ctx->d_inv_mod;
+        a.kdim = ctx->k;
+        if (fuse)
+        {
+            if (!forward || (fuse->ep_dest && (ctx->log_n < 12 || !lazy)))
+                return fail(CAT_ERR_LOGIC, "unsupported fused transform");
+            a.src = fuse->src;
+            a.src_stride = fuse->src_stride;
+            a.src_kind = (u32)fuse->src_kind;
+            a.src_qidx = fuse->src_qidx;
+            a.ep_other = fuse->ep_other;
+            a.ep_dest = fuse->ep_dest;
+            a.ep_other_b = fuse->ep_other_b;
+            a.ep_other_s = fuse->ep_other_s;
+            a.ep_dest_b = fuse->ep_dest_b;
+            a.ep_dest_s = fuse->ep_dest_s;
+            a.ep_S = fuse->ep_S;
+            a.ep_acc = (u32)fuse->ep_acc;
+            a.ep_qidx = fuse->ep_qidx;
+        }
         // N = 2 has odd-aligned twiddle groups nowhere, but keep the tiny sizes on the exact path: nothing to gain
         if (exact || ctx->log_n < 2)
         {
