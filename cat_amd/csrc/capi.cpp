@@ -741,28 +741,24 @@ cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, co
         return fail(CAT_ERR_INVALID_ARG, "Galois element is not valid");
     if (batch == 0)
         return CAT_OK;
-    // temp layout: [batch][2][L][N] permuted copy; c0 <- perm(c0), target <- perm(c1), c1 <- 0 (:2410-2449).
-    // The permuted copy lives in a caller-invisible buffer that must survive launch_switch_key's own
-    // workspace use, so it is carved from the same workspace block, after the key-switch region.
-    const size_t N = ctx->n, ctw = (size_t)2 * L * N;
+    // perm = [batch][2][L][N] permuted copy of the ciphertexts; c0 <- perm(c0), c1 <- 0 and the key switch reads its
+    // target perm(c1) in place, one ciphertext stride apart (:2410-2449).  The permuted copy must survive
+    // launch_switch_key's own workspace use, so it is carved from the same block, after the key-switch region.
+    const size_t N = ctx->n, ctw = (size_t)2 * L * N, lw = (size_t)L * N * sizeof(u64);
     const size_t ks_words = (size_t)batch * ((size_t)L + (size_t)(L + 1) * L + 2 * (L + 1) + 2 * L) * N;
-    u64 *ws = (u64 *)workspace(ctx, (ks_words + (size_t)batch * (ctw + L * N)) * sizeof(u64));
+    u64 *ws = (u64 *)workspace(ctx, (ks_words + (size_t)batch * ctw) * sizeof(u64));
     if (!ws)
         return CAT_ERR_NOMEM;
-    u64 *perm = ws + ks_words, *tgt = perm + (size_t)batch * ctw;
+    u64 *perm = ws + ks_words;
+    const u64 *tgt = perm + (size_t)L * N;
     const bool ntt = ctx->scheme == CAT_SCHEME_CKKS;
     st = launch_galois(ctx, ntt, (const u64 *)ct, perm, elt, ctx->identity_map(), L, batch * 2, (hipStream_t)s);
     if (st != CAT_OK)
         return st;
-    for (uint32_t b = 0; b < batch; ++b)
-    {
-        u64 *c = (u64 *)ct + b * ctw;
-        CAT_HIP(hipMemcpyAsync(c, perm + b * ctw, L * N * sizeof(u64), hipMemcpyDeviceToDevice, (hipStream_t)s));
-        CAT_HIP(hipMemcpyAsync(tgt + (size_t)b * L * N, perm + b * ctw + L * N, L * N * sizeof(u64),
-                               hipMemcpyDeviceToDevice, (hipStream_t)s));
-        CAT_HIP(hipMemsetAsync(c + L * N, 0, L * N * sizeof(u64), (hipStream_t)s));
-    }
-    return launch_switch_key(ctx, (u64 *)ct, tgt, (const u64 *)key, L, batch, ctw, (size_t)L * N, (hipStream_t)s);
+    CAT_HIP(hipMemcpy2DAsync(ct, ctw * sizeof(u64), perm, ctw * sizeof(u64), lw, batch, hipMemcpyDeviceToDevice,
+                             (hipStream_t)s));
+    CAT_HIP(hipMemset2DAsync((u64 *)ct + (size_t)L * N, ctw * sizeof(u64), 0, lw, batch, (hipStream_t)s));
+    return launch_switch_key(ctx, (u64 *)ct, tgt, (const u64 *)key, L, batch, ctw, ctw, (hipStream_t)s);
 }
 
 } // extern "C"
