@@ -124,28 +124,54 @@ struct __attribute__((aligned(8))) MulOp3
     u32 q1;
 };
 
-// nq = 2^64 - q.  The high-word cross terms are accumulated first, shifted into the upper word, and the low-word
-// chain is accumulated on top: the result is born in one natural register pair (no recombination moves).
+// nq = 2^64 - q.  Two independent v_mad_u64_u32 chains: the low-word products (a natural register pair) and the
+// high-word cross terms, whose low word is added into the upper word by one 32-bit add (no pair building).
 __device__ __forceinline__ u64 mul_split(u64 x, u64 W0, u64 W1, u32 Q0, u32 Q1, u64 nq)
 {
-    u64 E;
+    u64 L, C;
     u32 h0, h1;
-    asm("v_mul_hi_u32 %1, %3, %9\n\t"
-        "v_mul_hi_u32 %2, %4, %10\n\t"
-        "v_mad_u64_u32 %0, vcc, %3, %6, 0\n\t"
-        "v_mad_u64_u32 %0, vcc, %4, %8, %0\n\t"
-        "v_mad_u64_u32 %0, vcc, %1, %12, %0\n\t"
+    asm("v_mul_hi_u32 %2, %4, %10\n\t"
+        "v_mul_hi_u32 %3, %5, %11\n\t"
+        "v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %6, 0\n\t"
+        "v_mad_u64_u32 %1, vcc, %5, %9, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %5, %8, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %2, %13, %1\n\t"
         "v_mad_u64_u32 %0, vcc, %2, %12, %0\n\t"
-        "v_lshlrev_b64 %0, 32, %0\n\t"
-        "v_mad_u64_u32 %0, vcc, %3, %5, %0\n\t"
-        "v_mad_u64_u32 %0, vcc, %4, %7, %0\n\t"
-        "v_mad_u64_u32 %0, vcc, %1, %11, %0\n\t"
-        "v_mad_u64_u32 %0, vcc, %2, %11, %0"
-        : "=&v"(E), "=&v"(h0), "=&v"(h1)
+        "v_mad_u64_u32 %1, vcc, %3, %13, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, %12, %0"
+        : "=&v"(L), "=&v"(C), "=&v"(h0), "=&v"(h1)
         : "v"((u32)x), "v"((u32)(x >> 32)), "v"((u32)W0), "v"((u32)(W0 >> 32)), "v"((u32)W1), "v"((u32)(W1 >> 32)),
           "v"(Q0), "v"(Q1), "v"((u32)nq), "v"((u32)(nq >> 32))
         : "vcc");
-    return E;
+    u32 hi = (u32)(L >> 32);
+    asm("v_add_u32 %0, %0, %1" : "+v"(hi) : "v"((u32)C));
+    return ((u64)hi << 32) | (u32)L;
+}
+
+// a + x*w in the same lazy sense (result < a + 4q): two independent chains -- the low-word products accumulate on
+// top of `a`, the high-word cross terms on their own -- joined by ONE 32-bit add into the upper word.
+__device__ __forceinline__ u64 mul_split_add(u64 x, u64 W0, u64 W1, u32 Q0, u32 Q1, u64 nq, u64 a)
+{
+    u64 L, C;
+    u32 h0, h1;
+    asm("v_mul_hi_u32 %2, %4, %10\n\t"
+        "v_mul_hi_u32 %3, %5, %11\n\t"
+        "v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %6, %14\n\t"
+        "v_mad_u64_u32 %1, vcc, %5, %9, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %5, %8, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %2, %13, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %2, %12, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %3, %13, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, %12, %0"
+        : "=&v"(L), "=&v"(C), "=&v"(h0), "=&v"(h1)
+        : "v"((u32)x), "v"((u32)(x >> 32)), "v"((u32)W0), "v"((u32)(W0 >> 32)), "v"((u32)W1), "v"((u32)(W1 >> 32)),
+          "v"(Q0), "v"(Q1), "v"((u32)nq), "v"((u32)(nq >> 32)), "v"(a)
+        : "vcc");
+    u32 hi = (u32)(L >> 32);
+    asm("v_add_u32 %0, %0, %1" : "+v"(hi) : "v"((u32)C));
+    return ((u64)hi << 32) | (u32)L;
 }
 
 // 64-bit add as one v_lshl_add_u64 (the compiler prefers a two-instruction carry chain for x + constant)
@@ -156,9 +182,21 @@ __device__ __forceinline__ u64 add64(u64 a, u64 b)
     return r;
 }
 
+// 2a + b as one v_lshl_add_u64
+__device__ __forceinline__ u64 shl1_add64(u64 a, u64 b)
+{
+    u64 r;
+    asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ u64 mul_split(u64 x, const MulOp3 &w, u64 nq)
 {
     return mul_split(x, w.w0, w.w1, w.q0, w.q1, nq);
+}
+__device__ __forceinline__ u64 mul_split_add(u64 x, const MulOp3 &w, u64 nq, u64 a)
+{
+    return mul_split_add(x, w.w0, w.w1, w.q0, w.q1, nq, a);
 }
 
 // Per-modulus constants of the NTT kernels (both arithmetic flavours)

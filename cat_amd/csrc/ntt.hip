@@ -120,9 +120,8 @@ namespace
         u64 half, fix;
         int mode;        // 0 plain, 1 reduce modulo q, 2 round-and-fix
         bool reduce2;
-        __device__ __forceinline__ u64 operator()(u32 i) const
+        __device__ __forceinline__ u64 derive(u64 v) const
         {
-            u64 v = p[i];
             if (mode == 1)
                 v = barrett64(v, q, ratio1);
             else if (mode == 2)
@@ -133,6 +132,22 @@ namespace
                 v += fix;
             }
             return v;
+        }
+        __device__ __forceinline__ u64 operator()(u32 i) const { return derive(p[i]); }
+        // 16 values at once: every load is issued before the (wave-uniform) mode is looked at, so the loads stay
+        // one batch with one wait instead of sixteen dependent round trips
+        template <class Index>
+        __device__ __forceinline__ void load16(u64 (&x)[16], Index index) const
+        {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                x[e] = p[index(e)];
+            if (mode != 0)
+            {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    x[e] = derive(x[e]);
+            }
         }
     };
 
@@ -176,7 +191,7 @@ namespace
         typedef const MulOp *Table;
         struct Mod
         {
-            u64 q, K, negK;
+            u64 q, K, negK, nq;
             MulOp inv_n, inv_n_w;
         };
         __device__ static __forceinline__ Mod mod(const NttMod &m)
@@ -185,6 +200,7 @@ namespace
             r.q = m.q;
             r.K = m.q << 1;
             r.negK = 0 - r.K;
+            r.nq = 0 - m.q;
             r.inv_n = m.inv_n;
             r.inv_n_w = m.inv_n_w;
             return r;
@@ -204,16 +220,20 @@ namespace
         {
             return mul_lazy(x, w, m.q);
         }
+        __device__ static __forceinline__ u64 mul_add(u64 x, const Tw &w, const Mod &m, u64 a)
+        {
+            return add64(a, mul_lazy(x, w, m.q));
+        }
         __device__ static __forceinline__ Tw inv_n(const Mod &m) { return m.inv_n; }
         __device__ static __forceinline__ Tw inv_n_w(const Mod &m) { return m.inv_n_w; }
         // forward values are < 2K = 4q, inverse values < K = 2q
         __device__ static __forceinline__ u64 finish_fwd(u64 x, const Mod &m, bool lazy)
         {
-            return lazy ? x : csub(csub(x, m.K), m.q);
+            return lazy ? x : guard(guard(x, m.K, m.negK), m.q, m.nq);
         }
         __device__ static __forceinline__ u64 finish_inv(u64 x, const Mod &m, bool lazy)
         {
-            return lazy ? x : csub(x, m.q);
+            return lazy ? x : guard(x, m.q, m.nq);
         }
     };
 
@@ -279,41 +299,54 @@ namespace
         {
             return mul_split(x, w, m.nq);
         }
+        __device__ static __forceinline__ u64 mul_add(u64 x, const Tw &w, const Mod &m, u64 a)
+        {
+            return mul_split_add(x, w, m.nq, a);
+        }
         __device__ static __forceinline__ Tw inv_n(const Mod &m) { return m.inv_n; }
         __device__ static __forceinline__ Tw inv_n_w(const Mod &m) { return m.inv_n_w; }
         // forward values are < 2K = 8q, inverse values < K = 4q; contracts: lazy forward < 4q, lazy inverse < 2q
         __device__ static __forceinline__ u64 finish_fwd(u64 x, const Mod &m, bool lazy)
         {
-            x = csub(x, m.K);
-            return lazy ? x : csub(csub(x, m.q << 1), m.q);
+            x = guard(x, m.K, m.negK);
+            return lazy ? x : guard(guard(x, m.q << 1, m.nq << 1), m.q, m.nq);
         }
         __device__ static __forceinline__ u64 finish_inv(u64 x, const Mod &m, bool lazy)
         {
-            x = csub(x, m.q << 1);
-            return lazy ? x : csub(x, m.q);
+            x = guard(x, m.q << 1, m.nq << 1);
+            return lazy ? x : guard(x, m.q, m.nq);
         }
     };
 
     // ---- 16-point register networks ---------------------------------------------------------------
+#ifndef TW_CHUNK
+#define TW_CHUNK 8 // 4 saves ~7 VGPRs in the forward kernels but measured slower on MI355X
+#endif
     // Forward (Cooley-Tukey) local stage S: register gap 8 >> S, 2^S twiddles tw[(base << S) + g].
     template <class P, int S>
     __device__ __forceinline__ void fwd_stage16(u64 (&x)[16], const typename P::Table &tw, u32 base,
                                                 const typename P::Mod &m)
     {
         constexpr int gap = 8 >> S;
-        typename P::Tw w[1 << S];
-        P::template load<(1 << S)>(tw, base << S, w);
+        constexpr int CNT = 1 << S, CH = CNT < TW_CHUNK ? CNT : TW_CHUNK; // twiddles are fetched CH at a time
 #pragma unroll
-        for (int g = 0; g < (1 << S); ++g)
+        for (int g0 = 0; g0 < CNT; g0 += CH)
         {
+            typename P::Tw w[CH];
+            P::template load<CH>(tw, (base << S) + g0, w);
 #pragma unroll
-            for (int j = 0; j < gap; ++j)
+            for (int g = g0; g < g0 + CH; ++g)
             {
-                const int i0 = g * 2 * gap + j;
-                const u64 u = guard(x[i0], m.K, m.negK);
-                const u64 v = P::mul(x[i0 + gap], w[g], m);
-                x[i0] = add64(u, v);
-                x[i0 + gap] = add64(u, m.K) - v;
+#pragma unroll
+                for (int j = 0; j < gap; ++j)
+                {
+                    // X' = u + w*Y with u folded into the multiply chain; Y' = u - w*Y + K = 2u + K - X'
+                    const int i0 = g * 2 * gap + j;
+                    const u64 u = guard(x[i0], m.K, m.negK);
+                    const u64 s = P::mul_add(x[i0 + gap], w[g - g0], m, u);
+                    x[i0] = s;
+                    x[i0 + gap] = shl1_add64(u, m.K) - s;
+                }
             }
         }
     }
@@ -324,18 +357,23 @@ namespace
                                                 const typename P::Mod &m)
     {
         constexpr int gap = 1 << S;
-        typename P::Tw w[8 >> S];
-        P::template load<(8 >> S)>(tw, root0, w);
+        constexpr int CNT = 8 >> S, CH = CNT < TW_CHUNK ? CNT : TW_CHUNK;
 #pragma unroll
-        for (int g = 0; g < (8 >> S); ++g)
+        for (int g0 = 0; g0 < CNT; g0 += CH)
         {
+            typename P::Tw w[CH];
+            P::template load<CH>(tw, root0 + g0, w);
 #pragma unroll
-            for (int j = 0; j < gap; ++j)
+            for (int g = g0; g < g0 + CH; ++g)
             {
-                const int i0 = g * 2 * gap + j;
-                const u64 u = x[i0], v = x[i0 + gap];
-                x[i0] = guard(add64(u, v), m.K, m.negK);
-                x[i0 + gap] = P::mul(add64(u, m.K) - v, w[g], m);
+#pragma unroll
+                for (int j = 0; j < gap; ++j)
+                {
+                    const int i0 = g * 2 * gap + j;
+                    const u64 u = x[i0], v = x[i0 + gap];
+                    x[i0] = guard(add64(u, v), m.K, m.negK);
+                    x[i0 + gap] = P::mul(add64(u, m.K) - v, w[g - g0], m);
+                }
             }
         }
     }
@@ -382,12 +420,7 @@ namespace
         u64 x[16];
         if (K1 > 0)
         {
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-            {
-                const u32 row = (e >> (4 - K1)) * 16 + tau * SUB + (e & (SUB - 1));
-                x[e] = in(row * ROW_LEN + c);
-            }
+            in.load16(x, [&](int e) { return ((e >> (4 - K1)) * 16 + tau * SUB + (e & (SUB - 1))) * ROW_LEN + c; });
             if (K1 > 0) fwd_stage16<P, 0>(x, tw, 1, m);
             if (K1 > 1) fwd_stage16<P, 1>(x, tw, 1, m);
             if (K1 > 2) fwd_stage16<P, 2>(x, tw, 1, m);
@@ -405,9 +438,7 @@ namespace
         }
         else
         {
-#pragma unroll
-            for (int l = 0; l < 16; ++l)
-                x[l] = in((tau * 16 + l) * ROW_LEN + c);
+            in.load16(x, [&](int l) { return (tau * 16 + l) * ROW_LEN + c; });
         }
         const u32 base = (1u << K1) + tau;
         fwd_stage16<P, 0>(x, tw, base, m);
@@ -537,7 +568,7 @@ namespace
 
     // ---- inverse, pass 2: columns --------------------------------------------------------------------------
     template <class P, int LOGN1>
-    __global__ __launch_bounds__(256) void ntt_inv_cols(NttArgs a)
+    __global__ __launch_bounds__(256, 4) void ntt_inv_cols(NttArgs a)
     {
         constexpr int K1 = LOGN1 - 4;
         constexpr int N1 = 1 << LOGN1;
