@@ -112,6 +112,7 @@ namespace cat
         uint32_t ep_S = 1;
         int ep_acc = 0;
         uint32_t ep_qidx = 0;
+        bool first_pass_only = false; // forward, N >= 4096: run the column pass alone (the caller finishes the rows)
     };
     // general form: objects `poly_stride` words apart; limb j uses modulus map.id[j / limb_group];
     // skip_diag skips limbs with j % limb_group == j / limb_group (key switching's I == J operands)

@@ -11,6 +11,7 @@
 //  step 4  mod-down: INTT_P(t_last), +P/2, Barrett-64; per limb: reduce, +fix,
 //          NTT (CKKS) / INTT of the product (BFV), subtract, * P^-1, add to ct       :2759-2818
 #include "context.hpp"
+#include <cstdlib>
 
 namespace
 {
@@ -86,6 +87,248 @@ namespace
                 r1.y = barrett128(lo[b][3], hi[b][3], m.q, m.ratio0, m.ratio1);
                 o[0] = r0;
                 o[(u64)(g.d + 1) << (g.log_n - 1)] = r1;
+            }
+        }
+    }
+
+    // ---- fused second NTT pass + inner product (N >= 4096) --------------------------------------------------
+    // One workgroup owns 8 rows (2048 coefficients) of ONE output limb I of one ciphertext and walks over all
+    // decomposition digits J: for each digit it finishes the forward transform of ext[I][J] (the last 8 stages,
+    // rows of 256; the first pass ran as ntt_fwd_cols with the modulus raise fused) and multiplies the result
+    // straight from registers into the 128-bit accumulators of both key components.  The transformed extended
+    // limbs -- d (d+1) N words, the largest buffer of the call -- are never written or re-read.
+    //  * 8 coefficients per thread (three register rounds of 3 + 3 + 2 stages), two digits in flight per thread:
+    //    they share every twiddle fetch and give the VALU two independent chains.
+    //  * The row twiddles do not depend on the digit: the workgroup stages its 8 x 255 of them (split-Shoup form,
+    //    48 KB) in LDS once and reads them 12 times; the vector-memory queue then carries only the two streams
+    //    (digit data, key), so the compiler's counted waits never block on a twiddle behind an HBM load.
+    //  * A wave owns two rows and exchanges them through its own 4 KB of LDS (wave-level sync only); both
+    //    exchanges use XOR layouts that are conflict-free for their write and their read pattern.
+    //  * Workgroup order: the `batch` workgroups that read the same key tile are 8 ids apart, i.e. on the same
+    //    XCD at the same time, so the key tile comes from HBM once and from that XCD's L2 afterwards.
+    constexpr int RM_ROWS = 8;
+    constexpr int RM_TW_WORDS = 3 * RM_ROWS * 256; // [w0 | w1 | q0,q1][row][entry]; entry (1 << S) - 1 + G
+    constexpr int RM_X_WORDS = RM_ROWS * 256;
+
+    struct RowsMacArgs
+    {
+        const u64 *ext;    // [batch][d+1][d][N], first pass done
+        const u64 *target; // [batch][d][N] original (NTT form) for CKKS I == J
+        const u64 *key;    // [k-1][2][k][N]
+        u64 *prod;         // [batch][2][d+1][N]
+        const DevMod *mods;
+        const NttMod *nmods;
+        const u64 *tw3;    // [n_mod][3][N] forward split-Shoup tables
+        u32 d, k, log_n, batch;
+        int use_diag;
+        u64 target_stride;
+        u32 groups;        // (d+1) * N / 2048
+    };
+
+    __device__ __forceinline__ u64 rm_guard(u64 x, u64 K, u64 negK)
+    {
+        const u64 t = add64(x, negK);
+        return x >= K ? t : x;
+    }
+
+    // one radix-2 stage over the 8 registers of ND digits: CNT twiddles, register gap 4 / CNT
+    template <int ND, int CNT>
+    __device__ __forceinline__ void rm_stage(u64 (&x)[ND][8], const u64 *tw, u32 entry, u64 K, u64 negK, u64 nq)
+    {
+        constexpr int gap = 4 / CNT;
+        MulOp3 w[CNT];
+#pragma unroll
+        for (int g = 0; g < CNT; ++g)
+        {
+            const u64 qq = tw[2 * RM_ROWS * 256 + entry + g];
+            w[g].w0 = tw[entry + g];
+            w[g].w1 = tw[RM_ROWS * 256 + entry + g];
+            w[g].q0 = (u32)qq;
+            w[g].q1 = (u32)(qq >> 32);
+        }
+#pragma unroll
+        for (int g = 0; g < CNT; ++g)
+#pragma unroll
+            for (int j = 0; j < gap; ++j)
+#pragma unroll
+                for (int n = 0; n < ND; ++n)
+                {
+                    const int i0 = g * 2 * gap + j;
+                    const u64 u = rm_guard(x[n][i0], K, negK);
+                    const u64 v = mul_split_add(x[n][i0 + gap], w[g], nq, u);
+                    x[n][i0] = v;
+                    x[n][i0 + gap] = shl1_add64(u, K) - v;
+                }
+    }
+
+    __device__ __forceinline__ void rm_wave_sync()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // last 8 stages of ND limb-rows held as x[n][a] = row[a * 32 + t]; result x[n][u] = row[8 t + u], values < 4q
+    template <int ND>
+    __device__ __forceinline__ void rm_rows(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q)
+    {
+        const u64 K = q << 2, negK = 0 - K, nq = 0 - q;
+        rm_stage<ND, 1>(x, tw, 0, K, negK, nq);
+        rm_stage<ND, 2>(x, tw, 1, K, negK, nq);
+        rm_stage<ND, 4>(x, tw, 3, K, negK, nq);
+        const u32 A = t >> 2, c = t & 3;
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+        {
+            rm_wave_sync(); // the previous reads of this region are done
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+                xs[(a << 5) | (((t >> 2) ^ a) << 2) | c] = x[n][a]; // element a*32 + t
+            rm_wave_sync();
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                x[n][b] = xs[(A << 5) | ((b ^ A) << 2) | c]; // element A*32 + 4b + c
+        }
+        rm_stage<ND, 1>(x, tw, 7 + A, K, negK, nq);
+        rm_stage<ND, 2>(x, tw, 15 + 2 * A, K, negK, nq);
+        rm_stage<ND, 4>(x, tw, 31 + 4 * A, K, negK, nq);
+        const u32 bh = t & 3; // reader t = A*4 + b_hi holds elements 8t + u
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+        {
+            rm_wave_sync();
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                xs[((((b & 1) << 2) | c) << 5) | (A << 2) | ((b >> 1) ^ c)] = x[n][b];
+            rm_wave_sync();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                x[n][u] = xs[(u << 5) | (A << 2) | (bh ^ (u & 3))];
+        }
+        rm_stage<ND, 2>(x, tw, 63 + 2 * t, K, negK, nq);
+        rm_stage<ND, 4>(x, tw, 127 + 4 * t, K, negK, nq);
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                x[n][u] = rm_guard(x[n][u], K, negK);
+    }
+
+    __device__ __forceinline__ void rm_load8(u64 (&v)[8], const u64 *p)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const ulonglong2 w = reinterpret_cast<const ulonglong2 *>(p)[i];
+            v[2 * i] = w.x;
+            v[2 * i + 1] = w.y;
+        }
+    }
+
+    __global__ __launch_bounds__(256, 2) void ks_rows_mac_kernel(RowsMacArgs g)
+    {
+        __shared__ u64 lds[RM_TW_WORDS + RM_X_WORDS];
+        // id -> (group, ciphertext): ids 8 apart share the group (= the key tile) and the XCD
+        const u32 chunk = blockIdx.x / (8 * g.batch), within = blockIdx.x - chunk * 8 * g.batch;
+        const u32 b = within >> 3, grp = chunk * 8 + (within & 7);
+        if (grp >= g.groups)
+            return;
+        const u32 n1 = 1u << (g.log_n - 8), tiles = n1 / RM_ROWS;
+        const u32 I = grp / tiles, tile = grp - I * tiles;
+        const u32 ki = I == g.d ? g.k - 1 : I;
+        const u64 q = g.nmods[ki].q;
+        // stage the twiddles of the 8 rows: entry e = (1 << S) - 1 + G  <-  table[((n1 + row) << S) + G]
+        {
+            const u64 *tb = g.tw3 + ((size_t)ki * 3 << g.log_n);
+            const u32 e = threadIdx.x;
+            if (e < 255)
+            {
+                const u32 S = 31 - __clz(e + 1), G = e + 1 - (1u << S);
+#pragma unroll
+                for (int r = 0; r < RM_ROWS; ++r)
+                {
+                    const u32 idx = ((n1 + tile * RM_ROWS + r) << S) + G;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        lds[(a * RM_ROWS + r) * 256 + e] = tb[((size_t)a << g.log_n) + idx];
+                }
+            }
+        }
+        __syncthreads();
+        const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const u32 rl = wave * 2 + (lane >> 5), t = lane & 31;
+        const u32 row = tile * RM_ROWS + rl;
+        const u64 *tw = lds + rl * 256;
+        u64 *xs = lds + RM_TW_WORDS + rl * 256;
+        const size_t N = (size_t)1 << g.log_n;
+        const size_t roff = (size_t)row * 256;
+
+        u64 lo[2][8], hi[2][8];
+#pragma unroll
+        for (int cidx = 0; cidx < 2; ++cidx)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                lo[cidx][u] = hi[cidx][u] = 0;
+        const u64 *kbase = g.key + (size_t)ki * N + roff + 8 * t;
+        const u64 *ebase = g.ext + ((size_t)b * (g.d + 1) + I) * g.d * N + roff + t;
+        auto mac = [&](const u64 (&xv)[8], u32 J) {
+#pragma unroll
+            for (int cidx = 0; cidx < 2; ++cidx)
+            {
+                u64 kv[8];
+                rm_load8(kv, kbase + (size_t)(J * 2 + cidx) * g.k * N);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    mac128(lo[cidx][u], hi[cidx][u], xv[u], kv[u]);
+            }
+        };
+        const bool diag = g.use_diag && I < g.d;
+        if (diag)
+        {
+            u64 xv[8];
+            rm_load8(xv, g.target + (size_t)b * g.target_stride + (size_t)I * N + roff + 8 * t);
+            mac(xv, I);
+        }
+        const u32 cnt = diag ? g.d - 1 : g.d;
+        u32 jj = 0;
+        for (; jj + 2 <= cnt; jj += 2)
+        {
+            const u32 J0 = (diag && jj >= I) ? jj + 1 : jj, J1 = (diag && jj + 1 >= I) ? jj + 2 : jj + 1;
+            u64 x[2][8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+            {
+                x[0][a] = ebase[(size_t)J0 * N + a * 32];
+                x[1][a] = ebase[(size_t)J1 * N + a * 32];
+            }
+            rm_rows<2>(x, tw, xs, t, q);
+            mac(x[0], J0);
+            mac(x[1], J1);
+        }
+        if (jj < cnt)
+        {
+            const u32 J0 = (diag && jj >= I) ? jj + 1 : jj;
+            u64 x[1][8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+                x[0][a] = ebase[(size_t)J0 * N + a * 32];
+            rm_rows<1>(x, tw, xs, t, q);
+            mac(x[0], J0);
+        }
+        // d < 256: the reference's lazy counter never triggers an intermediate reduction (:2619-2707)
+        const DevMod m = g.mods[ki];
+#pragma unroll
+        for (int cidx = 0; cidx < 2; ++cidx)
+        {
+            u64 *o = g.prod + (((size_t)b * 2 + cidx) * (g.d + 1) + I) * N + roff + 8 * t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                ulonglong2 r;
+                r.x = barrett128(lo[cidx][2 * i], hi[cidx][2 * i], m.q, m.ratio0, m.ratio1);
+                r.y = barrett128(lo[cidx][2 * i + 1], hi[cidx][2 * i + 1], m.q, m.ratio0, m.ratio1);
+                reinterpret_cast<ulonglong2 *>(o)[i] = r;
             }
         }
     }
@@ -320,6 +563,7 @@ namespace cat
         }
         // step 2: modulus raise fused into the first NTT pass (ntt.hip Source): ext is written once, already
         // half transformed, instead of being written by a raise kernel and re-read
+        const bool fused_mac = log_n >= 12 && !getenv("CAT_KS_UNFUSED");
         {
             LimbMap map{};
             for (u32 I = 0; I < rns; ++I)
@@ -327,12 +571,37 @@ namespace cat
             NttFuse raise;
             raise.src = coeff_target;
             raise.src_stride = ckks ? (u64)d * N : (u64)target_stride;
+            raise.first_pass_only = fused_mac;
             cat_status st = launch_ntt_ex(ctx, true, ext, map, rns * d, batch, true, (u64)rns * d * N, d, ckks, s, false,
                                           &raise);
             if (st != CAT_OK)
                 return st;
         }
-        // step 3
+        // step 3 (N >= 4096: together with the second NTT pass)
+        if (fused_mac)
+        {
+            RowsMacArgs g;
+            g.ext = ext;
+            g.target = target;
+            g.key = key;
+            g.prod = prod;
+            g.mods = ctx->d_mods;
+            g.nmods = ctx->d_nttmods;
+            g.tw3 = ctx->d_tw3_fwd;
+            g.d = d;
+            g.k = k;
+            g.log_n = log_n;
+            g.batch = batch;
+            g.use_diag = ckks ? 1 : 0;
+            g.target_stride = target_stride;
+            g.groups = (u32)((u64)rns * (N / (RM_ROWS * 256)));
+            const u64 blocks = (u64)((g.groups + 7) / 8) * 8 * batch;
+            if (blocks > 0x7fffffffu)
+                return fail(CAT_ERR_LOGIC, "invalid parameters");
+            hipLaunchKernelGGL(ks_rows_mac_kernel, dim3((u32)blocks), dim3(256), 0, s, g);
+            CAT_HIP(hipGetLastError());
+        }
+        else
         {
             MacArgs g;
             g.ext = ext;

@@ -719,7 +719,7 @@ namespace
     }
 
     template <class P>
-    cat_status launch_policy(cat_ctx *ctx, bool forward, NttArgs &a, hipStream_t s)
+    cat_status launch_policy(cat_ctx *ctx, bool forward, NttArgs &a, hipStream_t s, bool first_only)
     {
         const uint64_t n_lp = (uint64_t)a.n_limbs * a.n_polys;
         if (ctx->log_n < 12)
@@ -753,7 +753,8 @@ namespace
         if (forward)
         {
             cols();
-            hipLaunchKernelGGL((ntt_fwd_rows<P>), dim3((u32)row_blocks), dim3(256), 0, s, a);
+            if (!first_only)
+                hipLaunchKernelGGL((ntt_fwd_rows<P>), dim3((u32)row_blocks), dim3(256), 0, s, a);
         }
         else
         {
@@ -804,7 +805,8 @@ namespace cat
         a.kdim = ctx->k;
         if (fuse)
         {
-            if (!forward || (fuse->ep_dest && (ctx->log_n < 12 || !lazy)))
+            if (!forward || (fuse->ep_dest && (ctx->log_n < 12 || !lazy)) ||
+                (fuse->first_pass_only && (ctx->log_n < 12 || exact || fuse->ep_dest)))
                 return fail(CAT_ERR_LOGIC, "unsupported fused transform");
             a.src = fuse->src;
             a.src_stride = fuse->src_stride;
@@ -824,9 +826,9 @@ namespace cat
         if (exact || ctx->log_n < 2)
         {
             a.tw = forward ? (const void *)ctx->d_tw_fwd : (const void *)ctx->d_tw_inv;
-            return launch_policy<Exact>(ctx, forward, a, s);
+            return launch_policy<Exact>(ctx, forward, a, s, false);
         }
         a.tw = forward ? (const void *)ctx->d_tw3_fwd : (const void *)ctx->d_tw3_inv;
-        return launch_policy<Fast>(ctx, forward, a, s);
+        return launch_policy<Fast>(ctx, forward, a, s, fuse && fuse->first_pass_only);
     }
 } // namespace cat
