@@ -170,6 +170,7 @@ namespace
     }
 
     // last 8 stages of ND limb-rows held as x[n][a] = row[a * 32 + t]; result x[n][u] = row[8 t + u], values < 4q
+    // and < 2^62
     template <int ND>
     __device__ __forceinline__ void rm_rows(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q)
     {
@@ -213,6 +214,45 @@ namespace
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 x[n][u] = rm_guard(x[n][u], K, negK);
+        if (q >> 60) // 61-bit primes: rm_mac's bounds want the operand below 2^62, make it canonical
+        {
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    x[n][u] = rm_guard(rm_guard(x[n][u], q << 1, nq << 1), q, nq);
+        }
+    }
+
+    // 128-bit lazy accumulation without a 64x64 high product.  With a = a1 2^32 + a0 < 2^62 and b < 2^60 (the range
+    // guard in rm_rows and canonical key words):  a b = a0 b0 + (a0 b1 + a1 b0) 2^32 + a1 b1 2^64, where
+    //   lo  += a0 b0        one v_mad_u64_u32, its carry-out counted in `cc` (weight 2^64),
+    //   mid += a0 b1 + a1 b0   < 2^62.4 per term: two terms fit 64 bits, folded into lo/hi by fold(),
+    //   hi  += a1 b1        < 2^58 per term, no carry for up to 64 terms.
+    struct Acc
+    {
+        u64 lo, hi;
+        u32 cc;
+    };
+    __device__ __forceinline__ void rm_mac(Acc &acc, u64 &mid, u64 a, u64 b)
+    {
+        const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+        u64 carry;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc.lo), "=s"(carry) : "v"(a0), "v"(b0));
+        asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(acc.cc) : "s"(carry) : "vcc");
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc.hi) : "v"(a1), "v"(b1) : "vcc");
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0"
+            : "+v"(mid)
+            : "v"(a0), "v"(b1), "v"(a1), "v"(b0)
+            : "vcc");
+    }
+    __device__ __forceinline__ void rm_fold(Acc &acc, u64 mid)
+    {
+        const u64 t = acc.lo + (mid << 32);
+        acc.cc += t < acc.lo;
+        acc.lo = t;
+        acc.hi += mid >> 32;
     }
 
     __device__ __forceinline__ void rm_load8(u64 (&v)[8], const u64 *p)
@@ -264,23 +304,37 @@ namespace
         const size_t N = (size_t)1 << g.log_n;
         const size_t roff = (size_t)row * 256;
 
-        u64 lo[2][8], hi[2][8];
+        Acc acc[2][8];
 #pragma unroll
         for (int cidx = 0; cidx < 2; ++cidx)
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                lo[cidx][u] = hi[cidx][u] = 0;
+                acc[cidx][u].lo = acc[cidx][u].hi = 0, acc[cidx][u].cc = 0;
         const u64 *kbase = g.key + (size_t)ki * N + roff + 8 * t;
         const u64 *ebase = g.ext + ((size_t)b * (g.d + 1) + I) * g.d * N + roff + t;
-        auto mac = [&](const u64 (&xv)[8], u32 J) {
+        // one or two digits: their middle sums share one 64-bit word per accumulator and are folded once
+        auto mac = [&](const u64 (&x0)[8], u32 J0, const u64 (&x1)[8], u32 J1, bool two) {
 #pragma unroll
             for (int cidx = 0; cidx < 2; ++cidx)
             {
-                u64 kv[8];
-                rm_load8(kv, kbase + (size_t)(J * 2 + cidx) * g.k * N);
+                u64 kv[8], mid[8];
+                rm_load8(kv, kbase + (size_t)(J0 * 2 + cidx) * g.k * N);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    mac128(lo[cidx][u], hi[cidx][u], xv[u], kv[u]);
+                {
+                    mid[u] = 0;
+                    rm_mac(acc[cidx][u], mid[u], x0[u], kv[u]);
+                }
+                if (two)
+                {
+                    rm_load8(kv, kbase + (size_t)(J1 * 2 + cidx) * g.k * N);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        rm_mac(acc[cidx][u], mid[u], x1[u], kv[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    rm_fold(acc[cidx][u], mid[u]);
             }
         };
         const bool diag = g.use_diag && I < g.d;
@@ -288,7 +342,7 @@ namespace
         {
             u64 xv[8];
             rm_load8(xv, g.target + (size_t)b * g.target_stride + (size_t)I * N + roff + 8 * t);
-            mac(xv, I);
+            mac(xv, I, xv, I, false);
         }
         const u32 cnt = diag ? g.d - 1 : g.d;
         u32 jj = 0;
@@ -303,8 +357,7 @@ namespace
                 x[1][a] = ebase[(size_t)J1 * N + a * 32];
             }
             rm_rows<2>(x, tw, xs, t, q);
-            mac(x[0], J0);
-            mac(x[1], J1);
+            mac(x[0], J0, x[1], J1, true);
         }
         if (jj < cnt)
         {
@@ -314,7 +367,7 @@ namespace
             for (int a = 0; a < 8; ++a)
                 x[0][a] = ebase[(size_t)J0 * N + a * 32];
             rm_rows<1>(x, tw, xs, t, q);
-            mac(x[0], J0);
+            mac(x[0], J0, x[0], J0, false);
         }
         // d < 256: the reference's lazy counter never triggers an intermediate reduction (:2619-2707)
         const DevMod m = g.mods[ki];
@@ -326,8 +379,9 @@ namespace
             for (int i = 0; i < 4; ++i)
             {
                 ulonglong2 r;
-                r.x = barrett128(lo[cidx][2 * i], hi[cidx][2 * i], m.q, m.ratio0, m.ratio1);
-                r.y = barrett128(lo[cidx][2 * i + 1], hi[cidx][2 * i + 1], m.q, m.ratio0, m.ratio1);
+                const Acc &e0 = acc[cidx][2 * i], &e1 = acc[cidx][2 * i + 1];
+                r.x = barrett128(e0.lo, e0.hi + e0.cc, m.q, m.ratio0, m.ratio1);
+                r.y = barrett128(e1.lo, e1.hi + e1.cc, m.q, m.ratio0, m.ratio1);
                 reinterpret_cast<ulonglong2 *>(o)[i] = r;
             }
         }
