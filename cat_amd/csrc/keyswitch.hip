@@ -356,8 +356,37 @@ namespace
                 x[0][a] = ebase[(size_t)J0 * N + a * 32];
                 x[1][a] = ebase[(size_t)J1 * N + a * 32];
             }
+            // key words of component 0 are requested before the transform (behind the digit data in the memory
+            // queue), those of component 1 while component 0 is being accumulated
+            const u64 *kp0 = kbase + (size_t)(J0 * 2) * g.k * N, *kp1 = kbase + (size_t)(J1 * 2) * g.k * N;
+            u64 ka[8], kb[8];
+            rm_load8(ka, kp0);
+            rm_load8(kb, kp1);
             rm_rows<2>(x, tw, xs, t, q);
-            mac(x[0], J0, x[1], J1, true);
+#pragma unroll
+            for (int cidx = 0; cidx < 2; ++cidx)
+            {
+                u64 kc[8], kd[8], mid[8];
+                if (cidx == 0)
+                {
+                    rm_load8(kc, kp0 + (size_t)g.k * N);
+                    rm_load8(kd, kp1 + (size_t)g.k * N);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                {
+                    mid[u] = 0;
+                    rm_mac(acc[cidx][u], mid[u], x[0][u], ka[u]);
+                    rm_mac(acc[cidx][u], mid[u], x[1][u], kb[u]);
+                    rm_fold(acc[cidx][u], mid[u]);
+                }
+                if (cidx == 0)
+                {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        ka[u] = kc[u], kb[u] = kd[u];
+                }
+            }
         }
         if (jj < cnt)
         {
