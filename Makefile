@@ -3,7 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude
 SRC := cat_amd/csrc/capi.cpp cat_amd/csrc/ntt.hip cat_amd/csrc/polyops.hip cat_amd/csrc/keyswitch.hip cat_amd/csrc/bfv.hip
-HDR := include/cat_amd.h cat_amd/csrc/context.hpp cat_amd/csrc/host_math.hpp cat_amd/csrc/modarith.cuh
+HDR := include/cat_amd.h cat_amd/csrc/context.hpp cat_amd/csrc/host_math.hpp cat_amd/csrc/modarith.cuh cat_amd/csrc/rows8.cuh
 OBJ := $(patsubst cat_amd/csrc/%,build/%.o,$(SRC))
 LIB := cat_amd/lib/libcat_amd.so
 

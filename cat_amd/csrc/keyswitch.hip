@@ -11,6 +11,7 @@
 //  step 4  mod-down: INTT_P(t_last), +P/2, Barrett-64; per limb: reduce, +fix,
 //          NTT (CKKS) / INTT of the product (BFV), subtract, * P^-1, add to ct       :2759-2818
 #include "context.hpp"
+#include "rows8.cuh"
 #include <cstdlib>
 
 namespace
@@ -106,9 +107,6 @@ namespace
     //    exchanges use XOR layouts that are conflict-free for their write and their read pattern.
     //  * Workgroup order: the `batch` workgroups that read the same key tile are 8 ids apart, i.e. on the same
     //    XCD at the same time, so the key tile comes from HBM once and from that XCD's L2 afterwards.
-    constexpr int RM_ROWS = 8;
-    constexpr int RM_TW_WORDS = 3 * RM_ROWS * 256; // [w0 | w1 | q0,q1][row][entry]; entry (1 << S) - 1 + G
-    constexpr int RM_X_WORDS = RM_ROWS * 256;
 
     struct RowsMacArgs
     {
@@ -124,105 +122,6 @@ namespace
         u64 target_stride;
         u32 groups;        // (d+1) * N / 2048
     };
-
-    __device__ __forceinline__ u64 rm_guard(u64 x, u64 K, u64 negK)
-    {
-        const u64 t = add64(x, negK);
-        return x >= K ? t : x;
-    }
-
-    // one radix-2 stage over the 8 registers of ND digits: CNT twiddles, register gap 4 / CNT
-    template <int ND, int CNT>
-    __device__ __forceinline__ void rm_stage(u64 (&x)[ND][8], const u64 *tw, u32 entry, u64 K, u64 negK, u64 nq)
-    {
-        constexpr int gap = 4 / CNT;
-        MulOp3 w[CNT];
-#pragma unroll
-        for (int g = 0; g < CNT; ++g)
-        {
-            const u64 qq = tw[2 * RM_ROWS * 256 + entry + g];
-            w[g].w0 = tw[entry + g];
-            w[g].w1 = tw[RM_ROWS * 256 + entry + g];
-            w[g].q0 = (u32)qq;
-            w[g].q1 = (u32)(qq >> 32);
-        }
-#pragma unroll
-        for (int g = 0; g < CNT; ++g)
-#pragma unroll
-            for (int j = 0; j < gap; ++j)
-#pragma unroll
-                for (int n = 0; n < ND; ++n)
-                {
-                    const int i0 = g * 2 * gap + j;
-                    const u64 u = rm_guard(x[n][i0], K, negK);
-                    const u64 v = mul_split_add(x[n][i0 + gap], w[g], nq, u);
-                    x[n][i0] = v;
-                    x[n][i0 + gap] = shl1_add64(u, K) - v;
-                }
-    }
-
-    __device__ __forceinline__ void rm_wave_sync()
-    {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-
-    // last 8 stages of ND limb-rows held as x[n][a] = row[a * 32 + t]; result x[n][u] = row[8 t + u], values < 4q
-    // and < 2^62
-    template <int ND>
-    __device__ __forceinline__ void rm_rows(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q)
-    {
-        const u64 K = q << 2, negK = 0 - K, nq = 0 - q;
-        rm_stage<ND, 1>(x, tw, 0, K, negK, nq);
-        rm_stage<ND, 2>(x, tw, 1, K, negK, nq);
-        rm_stage<ND, 4>(x, tw, 3, K, negK, nq);
-        const u32 A = t >> 2, c = t & 3;
-#pragma unroll
-        for (int n = 0; n < ND; ++n)
-        {
-            rm_wave_sync(); // the previous reads of this region are done
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-                xs[(a << 5) | (((t >> 2) ^ a) << 2) | c] = x[n][a]; // element a*32 + t
-            rm_wave_sync();
-#pragma unroll
-            for (int b = 0; b < 8; ++b)
-                x[n][b] = xs[(A << 5) | ((b ^ A) << 2) | c]; // element A*32 + 4b + c
-        }
-        rm_stage<ND, 1>(x, tw, 7 + A, K, negK, nq);
-        rm_stage<ND, 2>(x, tw, 15 + 2 * A, K, negK, nq);
-        rm_stage<ND, 4>(x, tw, 31 + 4 * A, K, negK, nq);
-        const u32 bh = t & 3; // reader t = A*4 + b_hi holds elements 8t + u
-#pragma unroll
-        for (int n = 0; n < ND; ++n)
-        {
-            rm_wave_sync();
-#pragma unroll
-            for (int b = 0; b < 8; ++b)
-                xs[((((b & 1) << 2) | c) << 5) | (A << 2) | ((b >> 1) ^ c)] = x[n][b];
-            rm_wave_sync();
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                x[n][u] = xs[(u << 5) | (A << 2) | (bh ^ (u & 3))];
-        }
-        rm_stage<ND, 2>(x, tw, 63 + 2 * t, K, negK, nq);
-        rm_stage<ND, 4>(x, tw, 127 + 4 * t, K, negK, nq);
-#pragma unroll
-        for (int n = 0; n < ND; ++n)
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                x[n][u] = rm_guard(x[n][u], K, negK);
-        if (q >> 60) // 61-bit primes: rm_mac's bounds want the operand below 2^62, make it canonical
-        {
-#pragma unroll
-            for (int n = 0; n < ND; ++n)
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    x[n][u] = rm_guard(rm_guard(x[n][u], q << 1, nq << 1), q, nq);
-        }
-    }
 
     // 128-bit lazy accumulation without a 64x64 high product.  With a = a1 2^32 + a0 < 2^62 and b < 2^60 (the range
     // guard in rm_rows and canonical key words):  a b = a0 b0 + (a0 b1 + a1 b0) 2^32 + a1 b1 2^64, where
@@ -278,23 +177,7 @@ namespace
         const u32 I = grp / tiles, tile = grp - I * tiles;
         const u32 ki = I == g.d ? g.k - 1 : I;
         const u64 q = g.nmods[ki].q;
-        // stage the twiddles of the 8 rows: entry e = (1 << S) - 1 + G  <-  table[((n1 + row) << S) + G]
-        {
-            const u64 *tb = g.tw3 + ((size_t)ki * 3 << g.log_n);
-            const u32 e = threadIdx.x;
-            if (e < 255)
-            {
-                const u32 S = 31 - __clz(e + 1), G = e + 1 - (1u << S);
-#pragma unroll
-                for (int r = 0; r < RM_ROWS; ++r)
-                {
-                    const u32 idx = ((n1 + tile * RM_ROWS + r) << S) + G;
-#pragma unroll
-                    for (int a = 0; a < 3; ++a)
-                        lds[(a * RM_ROWS + r) * 256 + e] = tb[((size_t)a << g.log_n) + idx];
-                }
-            }
-        }
+        rm_stage_twiddles(lds, g.tw3 + ((size_t)ki * 3 << g.log_n), g.log_n, tile);
         __syncthreads();
         const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         const u32 rl = wave * 2 + (lane >> 5), t = lane & 31;
@@ -363,6 +246,7 @@ namespace
             rm_load8(ka, kp0);
             rm_load8(kb, kp1);
             rm_rows<2>(x, tw, xs, t, q);
+            rm_below_2_62<2>(x, q);
 #pragma unroll
             for (int cidx = 0; cidx < 2; ++cidx)
             {
@@ -396,6 +280,7 @@ namespace
             for (int a = 0; a < 8; ++a)
                 x[0][a] = ebase[(size_t)J0 * N + a * 32];
             rm_rows<1>(x, tw, xs, t, q);
+            rm_below_2_62<1>(x, q);
             mac(x[0], J0, x[0], J0, false);
         }
         // d < 256: the reference's lazy counter never triggers an intermediate reduction (:2619-2707)

@@ -26,6 +26,9 @@
 //
 // HBM traffic is 16 B/coefficient per pass (two passes); twiddles come from L2.
 #include "context.hpp"
+#include "rows8.cuh"
+#include <cstdlib>
+#include <type_traits>
 
 namespace
 {
@@ -518,6 +521,89 @@ namespace
             p[h * 16 + t] = s[h * 17 + t];
     }
 
+    // ---- forward, pass 2, poly-streaming form (Fast policy, no fused epilogue) ------------------------------
+    // A workgroup owns 8 rows of one limb at one position, stages their twiddles in LDS once (rows8.cuh) and
+    // streams the rows of `n_polys / chunks` polynomials through them, two polynomials in flight per thread and
+    // the next pair already requested.  Against ntt_fwd_rows: no per-tile twiddle traffic from L2 (3x the data
+    // volume there) and nothing but the data stream in the vector-memory queue.
+    template <int ND>
+    __device__ __forceinline__ void rows8_load(u64 (&x)[2][8], const u64 *const (&src)[2])
+    {
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+                x[n][a] = src[n][a * 32];
+    }
+
+    __global__ __launch_bounds__(256, 2) void ntt_fwd_rows8(NttArgs a, u32 chunks)
+    {
+        __shared__ u64 lds[RM_TW_WORDS + RM_X_WORDS];
+        const u32 n1 = 1u << (a.log_n - 8), tiles = n1 / RM_ROWS;
+        const u32 chunk = blockIdx.x % chunks, rest = blockIdx.x / chunks;
+        const u32 tile = rest % tiles, limb = rest / tiles;
+        const u32 grp = limb / a.limb_group;
+        if (a.skip_diag && limb - grp * a.limb_group == grp)
+            return;
+        const u32 mod = a.map.id[grp];
+        const u64 q = a.mods[mod].q, nq = 0 - q;
+        rm_stage_twiddles(lds, reinterpret_cast<const u64 *>(a.tw) + ((size_t)mod * 3 << a.log_n), a.log_n, tile);
+        __syncthreads();
+        const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const u32 rl = wave * 2 + (lane >> 5), t = lane & 31;
+        const u64 *tw = lds + rl * 256;
+        u64 *xs = lds + RM_TW_WORDS + rl * 256;
+        u64 *base = a.data + ((u64)limb << a.log_n) + (size_t)(tile * RM_ROWS + rl) * 256;
+        const bool lazy = a.lazy != 0;
+
+        const u32 pairs = (a.n_polys + 1) / 2;
+        u64 xn[2][8];
+        u32 pi = chunk;
+        if (pi < pairs)
+        {
+            const u64 *src[2] = {base + (u64)(2 * pi) * a.poly_stride + t,
+                                 base + (u64)(2 * pi + 1 < a.n_polys ? 2 * pi + 1 : 2 * pi) * a.poly_stride + t};
+            rows8_load<2>(xn, src);
+        }
+        for (; pi < pairs; pi += chunks)
+        {
+            u64 x[2][8];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    x[n][e] = xn[n][e];
+            const u32 nx = pi + chunks;
+            if (nx < pairs)
+            {
+                const u64 *src[2] = {base + (u64)(2 * nx) * a.poly_stride + t,
+                                     base + (u64)(2 * nx + 1 < a.n_polys ? 2 * nx + 1 : 2 * nx) * a.poly_stride + t};
+                rows8_load<2>(xn, src);
+            }
+            rm_rows<2>(x, tw, xs, t, q);
+            const bool two = 2 * pi + 1 < a.n_polys;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+            {
+                if (n == 1 && !two)
+                    break;
+                u64 *o = base + (u64)(2 * pi + n) * a.poly_stride + 8 * t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                {
+                    ulonglong2 r;
+                    r.x = x[n][2 * i], r.y = x[n][2 * i + 1];
+                    if (!lazy)
+                    {
+                        r.x = guard(guard(r.x, q << 1, nq << 1), q, nq);
+                        r.y = guard(guard(r.y, q << 1, nq << 1), q, nq);
+                    }
+                    reinterpret_cast<ulonglong2 *>(o)[i] = r;
+                }
+            }
+        }
+    }
+
     // ---- inverse, pass 1: rows ---------------------------------------------------------------------------
     template <class P>
     __global__ __launch_bounds__(256) void ntt_inv_rows(NttArgs a)
@@ -753,7 +839,21 @@ namespace
         if (forward)
         {
             cols();
-            if (!first_only)
+            if (first_only)
+                ;
+            else if (std::is_same<P, Fast>::value && !a.ep_dest && a.n_polys >= 4 && !getenv("CAT_NTT_ROWS16"))
+            {
+                // poly-streaming row pass: workgroups = limbs x 8-row positions x chunks of the polynomials
+                const u64 groups = (u64)a.n_limbs * (n1 / RM_ROWS);
+                u32 chunks = (u32)((8192 + groups - 1) / groups);
+                const u32 max_chunks = (a.n_polys + 1) / 2 / 2; // at least two pairs per workgroup
+                if (chunks > max_chunks)
+                    chunks = max_chunks;
+                if (chunks < 1)
+                    chunks = 1;
+                hipLaunchKernelGGL(ntt_fwd_rows8, dim3((u32)(groups * chunks)), dim3(256), 0, s, a, chunks);
+            }
+            else
                 hipLaunchKernelGGL((ntt_fwd_rows<P>), dim3((u32)row_blocks), dim3(256), 0, s, a);
         }
         else

@@ -1,0 +1,143 @@
+// Row pass of the forward negacyclic NTT with 8 coefficients per thread and the row twiddles in LDS.
+// Shared by the fused key-switch kernel (keyswitch.hip) and the poly-streaming row pass (ntt.hip).
+//
+// A workgroup of 256 threads owns RM_ROWS = 8 rows of 256 coefficients of one limb; a wave owns two of them.
+// The last 8 stages of SEAL's forward network (util/dwthandler.h:94-192) stay inside a row and their twiddles
+// tw[((n1 + row) << S) + G] (S = 0..7, G < 2^S) depend on the limb and the row only, not on the polynomial:
+// the workgroup stages them once (split-Shoup form, 3 x 8 x 256 words = 48 KB) and every further row of the
+// same limb and position reuses them from LDS.  Three register rounds of 3 + 3 + 2 stages; between them the wave
+// exchanges its rows through 4 KB of LDS with XOR layouts that are conflict-free for writer and reader.
+#pragma once
+#include "modarith.cuh"
+
+namespace
+{
+    constexpr int RM_ROWS = 8;
+    constexpr int RM_TW_WORDS = 3 * RM_ROWS * 256; // [w0 | w1 | q0,q1][row][entry]; entry (1 << S) - 1 + G
+    constexpr int RM_X_WORDS = RM_ROWS * 256;
+
+    // all 256 threads: lds[0 .. RM_TW_WORDS) <- twiddles of rows tile*8 .. tile*8+7; table = u64[3][N] of the limb
+    __device__ __forceinline__ void rm_stage_twiddles(u64 *lds, const u64 *table, u32 log_n, u32 tile)
+    {
+        const u32 n1 = 1u << (log_n - 8);
+        const u32 e = threadIdx.x;
+        if (e < 255)
+        {
+            const u32 S = 31 - __clz(e + 1), G = e + 1 - (1u << S);
+#pragma unroll
+            for (int r = 0; r < RM_ROWS; ++r)
+            {
+                const u32 idx = ((n1 + tile * RM_ROWS + r) << S) + G;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    lds[(a * RM_ROWS + r) * 256 + e] = table[((size_t)a << log_n) + idx];
+            }
+        }
+    }
+
+    __device__ __forceinline__ u64 rm_guard(u64 x, u64 K, u64 negK)
+    {
+        const u64 t = add64(x, negK);
+        return x >= K ? t : x;
+    }
+
+    // one radix-2 stage over the 8 registers of ND digits: CNT twiddles, register gap 4 / CNT
+    template <int ND, int CNT>
+    __device__ __forceinline__ void rm_stage(u64 (&x)[ND][8], const u64 *tw, u32 entry, u64 K, u64 negK, u64 nq)
+    {
+        constexpr int gap = 4 / CNT;
+        MulOp3 w[CNT];
+#pragma unroll
+        for (int g = 0; g < CNT; ++g)
+        {
+            const u64 qq = tw[2 * RM_ROWS * 256 + entry + g];
+            w[g].w0 = tw[entry + g];
+            w[g].w1 = tw[RM_ROWS * 256 + entry + g];
+            w[g].q0 = (u32)qq;
+            w[g].q1 = (u32)(qq >> 32);
+        }
+#pragma unroll
+        for (int g = 0; g < CNT; ++g)
+#pragma unroll
+            for (int j = 0; j < gap; ++j)
+#pragma unroll
+                for (int n = 0; n < ND; ++n)
+                {
+                    const int i0 = g * 2 * gap + j;
+                    const u64 u = rm_guard(x[n][i0], K, negK);
+                    const u64 v = mul_split_add(x[n][i0 + gap], w[g], nq, u);
+                    x[n][i0] = v;
+                    x[n][i0 + gap] = shl1_add64(u, K) - v;
+                }
+    }
+
+    __device__ __forceinline__ void rm_wave_sync()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // last 8 stages of ND limb-rows held as x[n][a] = row[a * 32 + t]; result x[n][u] = row[8 t + u], values < 4q
+    template <int ND>
+    __device__ __forceinline__ void rm_rows(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q)
+    {
+        const u64 K = q << 2, negK = 0 - K, nq = 0 - q;
+        rm_stage<ND, 1>(x, tw, 0, K, negK, nq);
+        rm_stage<ND, 2>(x, tw, 1, K, negK, nq);
+        rm_stage<ND, 4>(x, tw, 3, K, negK, nq);
+        const u32 A = t >> 2, c = t & 3;
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+        {
+            rm_wave_sync(); // the previous reads of this region are done
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+                xs[(a << 5) | (((t >> 2) ^ a) << 2) | c] = x[n][a]; // element a*32 + t
+            rm_wave_sync();
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                x[n][b] = xs[(A << 5) | ((b ^ A) << 2) | c]; // element A*32 + 4b + c
+        }
+        rm_stage<ND, 1>(x, tw, 7 + A, K, negK, nq);
+        rm_stage<ND, 2>(x, tw, 15 + 2 * A, K, negK, nq);
+        rm_stage<ND, 4>(x, tw, 31 + 4 * A, K, negK, nq);
+        const u32 bh = t & 3; // reader t = A*4 + b_hi holds elements 8t + u
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+        {
+            rm_wave_sync();
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                xs[((((b & 1) << 2) | c) << 5) | (A << 2) | ((b >> 1) ^ c)] = x[n][b];
+            rm_wave_sync();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                x[n][u] = xs[(u << 5) | (A << 2) | (bh ^ (u & 3))];
+        }
+        rm_stage<ND, 2>(x, tw, 63 + 2 * t, K, negK, nq);
+        rm_stage<ND, 4>(x, tw, 127 + 4 * t, K, negK, nq);
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                x[n][u] = rm_guard(x[n][u], K, negK);
+    }
+
+
+    // 61-bit primes: callers that want the row below 2^62 (rm_mac's bounds) make it canonical
+    template <int ND>
+    __device__ __forceinline__ void rm_below_2_62(u64 (&x)[ND][8], u64 q)
+    {
+        if (q >> 60)
+        {
+            const u64 nq = 0 - q;
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    x[n][u] = rm_guard(rm_guard(x[n][u], q << 1, nq << 1), q, nq);
+        }
+    }
+} // namespace
