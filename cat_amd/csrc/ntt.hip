@@ -582,24 +582,109 @@ namespace
             }
             rm_rows<2>(x, tw, xs, t, q);
             const bool two = 2 * pi + 1 < a.n_polys;
+            // third exchange: from 8 consecutive coefficients per thread to 16-byte pieces that are consecutive
+            // across the lanes of a row, so that every store instruction writes whole 512-byte runs
 #pragma unroll
             for (int n = 0; n < 2; ++n)
             {
                 if (n == 1 && !two)
                     break;
-                u64 *o = base + (u64)(2 * pi + n) * a.poly_stride + 8 * t;
+                rm_wave_sync();
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                {
+                    u64 v = x[n][u];
+                    if (!lazy)
+                        v = guard(guard(v, q << 1, nq << 1), q, nq);
+                    xs[(8 * t + u) ^ (t >> 2)] = v; // element e at e ^ ((e >> 5) & 7)
+                }
+                rm_wave_sync();
+                u64 *o = base + (u64)(2 * pi + n) * a.poly_stride;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                 {
-                    ulonglong2 r;
-                    r.x = x[n][2 * i], r.y = x[n][2 * i + 1];
-                    if (!lazy)
-                    {
-                        r.x = guard(guard(r.x, q << 1, nq << 1), q, nq);
-                        r.y = guard(guard(r.y, q << 1, nq << 1), q, nq);
-                    }
-                    reinterpret_cast<ulonglong2 *>(o)[i] = r;
+                    const u32 e = (i * 32 + t) * 2, sw = (2 * i + (t >> 4)) & 7;
+                    const ulonglong2 r = *reinterpret_cast<const ulonglong2 *>(xs + ((e ^ sw) & ~1u));
+                    ulonglong2 w;
+                    w.x = (sw & 1) ? r.y : r.x;
+                    w.y = (sw & 1) ? r.x : r.y;
+                    *reinterpret_cast<ulonglong2 *>(o + e) = w;
                 }
+            }
+        }
+    }
+
+    // ---- inverse, pass 1, poly-streaming form: the mirror image of ntt_fwd_rows8 ----------------------------
+    __global__ __launch_bounds__(256, 2) void ntt_inv_rows8(NttArgs a, u32 chunks)
+    {
+        __shared__ u64 lds[RM_TW_WORDS + RM_X_WORDS];
+        const u32 n1 = 1u << (a.log_n - 8), tiles = n1 / RM_ROWS;
+        const u32 chunk = blockIdx.x % chunks, rest = blockIdx.x / chunks;
+        const u32 tile = rest % tiles, limb = rest / tiles;
+        const u32 grp = limb / a.limb_group;
+        if (a.skip_diag && limb - grp * a.limb_group == grp)
+            return;
+        const u32 mod = a.map.id[grp];
+        const u64 q = a.mods[mod].q;
+        rm_stage_twiddles_inv(lds, reinterpret_cast<const u64 *>(a.tw) + ((size_t)mod * 3 << a.log_n), a.log_n, tile);
+        __syncthreads();
+        const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const u32 rl = wave * 2 + (lane >> 5), t = lane & 31;
+        const u64 *tw = lds + rl * 256;
+        u64 *xs = lds + RM_TW_WORDS + rl * 256;
+        u64 *base = a.data + ((u64)limb << a.log_n) + (size_t)(tile * RM_ROWS + rl) * 256;
+
+        // loads: 16-byte pieces consecutive across the lanes of a row, turned into 8 consecutive coefficients per
+        // thread through LDS (element e at e ^ ((e >> 5) & 7), as in the forward kernel's store side)
+        auto fetch = [&](ulonglong2 (&raw)[2][4], u32 pi) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+            {
+                const u64 *src = base + (u64)(2 * pi + n < a.n_polys ? 2 * pi + n : 2 * pi) * a.poly_stride;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    raw[n][i] = *reinterpret_cast<const ulonglong2 *>(src + (i * 32 + t) * 2);
+            }
+        };
+        const u32 pairs = (a.n_polys + 1) / 2;
+        ulonglong2 rn[2][4];
+        u32 pi = chunk;
+        if (pi < pairs)
+            fetch(rn, pi);
+        for (; pi < pairs; pi += chunks)
+        {
+            u64 x[2][8];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+            {
+                rm_wave_sync();
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                {
+                    const u32 e = (i * 32 + t) * 2, sw = (2 * i + (t >> 4)) & 7;
+                    ulonglong2 w;
+                    w.x = (sw & 1) ? rn[n][i].y : rn[n][i].x;
+                    w.y = (sw & 1) ? rn[n][i].x : rn[n][i].y;
+                    *reinterpret_cast<ulonglong2 *>(xs + ((e ^ sw) & ~1u)) = w;
+                }
+                rm_wave_sync();
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    x[n][u] = xs[(8 * t + u) ^ (t >> 2)];
+            }
+            if (pi + chunks < pairs)
+                fetch(rn, pi + chunks);
+            rm_rows_inv<2>(x, tw, xs, t, q);
+            const bool two = 2 * pi + 1 < a.n_polys;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+            {
+                if (n == 1 && !two)
+                    break;
+                u64 *o = base + (u64)(2 * pi + n) * a.poly_stride + t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    o[e * 32] = x[n][e];
             }
         }
     }
@@ -858,7 +943,19 @@ namespace
         }
         else
         {
-            hipLaunchKernelGGL((ntt_inv_rows<P>), dim3((u32)row_blocks), dim3(256), 0, s, a);
+            if (std::is_same<P, Fast>::value && a.n_polys >= 4 && !getenv("CAT_NTT_ROWS16"))
+            {
+                const u64 groups = (u64)a.n_limbs * (n1 / RM_ROWS);
+                u32 chunks = (u32)((8192 + groups - 1) / groups);
+                const u32 max_chunks = (a.n_polys + 1) / 2 / 2;
+                if (chunks > max_chunks)
+                    chunks = max_chunks;
+                if (chunks < 1)
+                    chunks = 1;
+                hipLaunchKernelGGL(ntt_inv_rows8, dim3((u32)(groups * chunks)), dim3(256), 0, s, a, chunks);
+            }
+            else
+                hipLaunchKernelGGL((ntt_inv_rows<P>), dim3((u32)row_blocks), dim3(256), 0, s, a);
             cols();
         }
         CAT_HIP(hipGetLastError());

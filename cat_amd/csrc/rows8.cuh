@@ -126,6 +126,96 @@ namespace
     }
 
 
+    // ---- inverse (Gentleman-Sande) counterpart: the FIRST 8 stages of SEAL's inverse network ------------------
+    // (util/dwthandler.h:203-357) stay inside a row; stage T (gap 2^T) uses inv_tw[N - (N >> T) + 1 + row (128 >> T) + G],
+    // G < 128 >> T.  LDS entry of (T, G): 256 - (256 >> T) + G.  `table` = u64[3][N] of the limb in the shifted
+    // inverse layout of the context (logical index i is stored at i - 1).
+    __device__ __forceinline__ void rm_stage_twiddles_inv(u64 *lds, const u64 *table, u32 log_n, u32 tile)
+    {
+        const u32 n = 1u << log_n;
+        const u32 e = threadIdx.x;
+        if (e < 255)
+        {
+            const u32 T = 7 - (31 - __clz(255 - e)), G = e - (256 - (256 >> T));
+#pragma unroll
+            for (int r = 0; r < RM_ROWS; ++r)
+            {
+                const u32 idx = n - (n >> T) + 1 + (tile * RM_ROWS + r) * (128 >> T) + G;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    lds[(a * RM_ROWS + r) * 256 + e] = table[((size_t)a << log_n) + idx - 1];
+            }
+        }
+    }
+
+    template <int ND, int CNT>
+    __device__ __forceinline__ void rm_stage_inv(u64 (&x)[ND][8], const u64 *tw, u32 entry, u64 K, u64 negK, u64 nq)
+    {
+        constexpr int gap = 4 / CNT;
+        MulOp3 w[CNT];
+#pragma unroll
+        for (int g = 0; g < CNT; ++g)
+        {
+            const u64 qq = tw[2 * RM_ROWS * 256 + entry + g];
+            w[g].w0 = tw[entry + g];
+            w[g].w1 = tw[RM_ROWS * 256 + entry + g];
+            w[g].q0 = (u32)qq;
+            w[g].q1 = (u32)(qq >> 32);
+        }
+#pragma unroll
+        for (int g = 0; g < CNT; ++g)
+#pragma unroll
+            for (int j = 0; j < gap; ++j)
+#pragma unroll
+                for (int n = 0; n < ND; ++n)
+                {
+                    const int i0 = g * 2 * gap + j;
+                    const u64 u = x[n][i0], v = x[n][i0 + gap];
+                    x[n][i0] = rm_guard(add64(u, v), K, negK);
+                    x[n][i0 + gap] = mul_split(add64(u, K) - v, w[g], nq);
+                }
+    }
+
+    // in: x[n][u] = row[8 t + u] (values < 4q); out: x[n][a] = row[a * 32 + t], values < 4q
+    template <int ND>
+    __device__ __forceinline__ void rm_rows_inv(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q)
+    {
+        const u64 K = q << 2, negK = 0 - K, nq = 0 - q;
+        const u32 A = t >> 2, c = t & 3, bh = t & 3;
+        rm_stage_inv<ND, 4>(x, tw, 0 + 4 * t, K, negK, nq);
+        rm_stage_inv<ND, 2>(x, tw, 128 + 2 * t, K, negK, nq);
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+        {
+            rm_wave_sync();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                xs[(u << 5) | (A << 2) | (bh ^ (u & 3))] = x[n][u]; // element 8t + u
+            rm_wave_sync();
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                x[n][b] = xs[((((b & 1) << 2) | c) << 5) | (A << 2) | ((b >> 1) ^ c)]; // element A*32 + 4b + c
+        }
+        rm_stage_inv<ND, 4>(x, tw, 192 + 4 * A, K, negK, nq);
+        rm_stage_inv<ND, 2>(x, tw, 224 + 2 * A, K, negK, nq);
+        rm_stage_inv<ND, 1>(x, tw, 240 + A, K, negK, nq);
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+        {
+            rm_wave_sync();
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                xs[(A << 5) | ((b ^ A) << 2) | c] = x[n][b];
+            rm_wave_sync();
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+                x[n][a] = xs[(a << 5) | (((t >> 2) ^ a) << 2) | c]; // element a*32 + t
+        }
+        rm_stage_inv<ND, 4>(x, tw, 248, K, negK, nq);
+        rm_stage_inv<ND, 2>(x, tw, 252, K, negK, nq);
+        rm_stage_inv<ND, 1>(x, tw, 254, K, negK, nq);
+    }
+
     // 61-bit primes: callers that want the row below 2^62 (rm_mac's bounds) make it canonical
     template <int ND>
     __device__ __forceinline__ void rm_below_2_62(u64 (&x)[ND][8], u64 q)
