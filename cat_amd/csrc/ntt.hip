@@ -321,6 +321,26 @@ namespace
         }
     };
 
+    // Column passes, Fast policy: the first log2(N1) <= 8 forward stages use table entries 1 .. N1-1, the last
+    // log2(N1) inverse stages the entries N - N1 + 1 .. N - 1 -- at most 255 twiddles per limb, the same for every
+    // column and polynomial.  A workgroup copies them to LDS (6 KB) and the butterflies read them with ds_read
+    // instead of sending 30 vector loads per thread to L2.
+    __device__ __forceinline__ Fast::Table stage_col_twiddles(u64 *twl, const Fast::Table &g, u32 log_n, bool inverse)
+    {
+        const u32 n = 1u << log_n;
+        const u32 first = inverse ? n - 256 + 1 : 0; // logical index of twl[0]
+        const u32 e = threadIdx.x;
+        twl[e] = g.w0[first + e];
+        twl[256 + e] = g.w1[first + e];
+        twl[512 + e] = g.qq[first + e];
+        Fast::Table t;
+        t.w0 = twl - first;
+        t.w1 = twl + 256 - first;
+        t.qq = twl + 512 - first;
+        return t;
+    }
+    __device__ __forceinline__ Exact::Table stage_col_twiddles(u64 *, const Exact::Table &g, u32, bool) { return g; }
+
     // ---- 16-point register networks ---------------------------------------------------------------
 #ifndef TW_CHUNK
 #define TW_CHUNK 8 // 4 saves ~7 VGPRs in the forward kernels but measured slower on MI355X
@@ -415,7 +435,8 @@ namespace
         if (w.skip)
             return;
         const typename P::Mod m = P::mod(a.mods[w.mod]);
-        const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, false);
+        __shared__ u64 twl[3 * 256];
+        const typename P::Table tw = stage_col_twiddles(twl, P::table(a.tw, w.mod, a.log_n, false), a.log_n, false);
         u64 *p = a.data + w.offset + w.tile * C;
         const Source in = source(a, w, w.tile * C);
 
@@ -424,6 +445,8 @@ namespace
         if (K1 > 0)
         {
             in.load16(x, [&](int e) { return ((e >> (4 - K1)) * 16 + tau * SUB + (e & (SUB - 1))) * ROW_LEN + c; });
+            if (std::is_same<P, Fast>::value)
+                __syncthreads(); // staged twiddles visible
             if (K1 > 0) fwd_stage16<P, 0>(x, tw, 1, m);
             if (K1 > 1) fwd_stage16<P, 1>(x, tw, 1, m);
             if (K1 > 2) fwd_stage16<P, 2>(x, tw, 1, m);
@@ -442,6 +465,8 @@ namespace
         else
         {
             in.load16(x, [&](int l) { return (tau * 16 + l) * ROW_LEN + c; });
+            if (std::is_same<P, Fast>::value)
+                __syncthreads();
         }
         const u32 base = (1u << K1) + tau;
         fwd_stage16<P, 0>(x, tw, base, m);
@@ -752,7 +777,8 @@ namespace
         if (w.skip)
             return;
         const typename P::Mod m = P::mod(a.mods[w.mod]);
-        const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, true);
+        __shared__ u64 twl[3 * 256];
+        const typename P::Table tw = stage_col_twiddles(twl, P::table(a.tw, w.mod, a.log_n, true), a.log_n, true);
         u64 *p = a.data + w.offset + w.tile * C;
         const u32 c = threadIdx.x % C, tau = threadIdx.x / C;
 
@@ -760,6 +786,8 @@ namespace
 #pragma unroll
         for (int l = 0; l < 16; ++l)
             x[l] = p[(tau * 16 + l) * ROW_LEN + c];
+        if (std::is_same<P, Fast>::value)
+            __syncthreads(); // staged twiddles visible
         // global stages 8..11
         inv_stage16<P, 0>(x, tw, n - (n >> 8) + 1 + tau * 8, m);
         inv_stage16<P, 1>(x, tw, n - (n >> 9) + 1 + tau * 4, m);
