@@ -80,8 +80,8 @@ def uniform_limbs(torch, primes, prefix, device, gen):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="ciphertext pairs per step per GPU")
     ap.add_argument("--limbs", type=int, default=24, help="ciphertext limbs L (key level has L+1 primes)")
     ap.add_argument("--ntt-polys", type=int, default=1024)

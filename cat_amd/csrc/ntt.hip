@@ -35,6 +35,9 @@ namespace
     constexpr int ROW_LEN = 256;      // N2
     constexpr int ROW_PITCH = 272;    // 256 + 256/16 padding words (bank-conflict-free transposes)
     constexpr int TILE_WORDS = 4096;
+#ifndef ROWS8_TARGET_BLOCKS
+#define ROWS8_TARGET_BLOCKS 8192 // poly-streaming row passes: workgroups aimed at (4096 and 16384 measured 1 % slower)
+#endif
 
     struct NttArgs
     {
@@ -958,7 +961,7 @@ namespace
             {
                 // poly-streaming row pass: workgroups = limbs x 8-row positions x chunks of the polynomials
                 const u64 groups = (u64)a.n_limbs * (n1 / RM_ROWS);
-                u32 chunks = (u32)((8192 + groups - 1) / groups);
+                u32 chunks = (u32)((ROWS8_TARGET_BLOCKS + groups - 1) / groups);
                 const u32 max_chunks = (a.n_polys + 1) / 2 / 2; // at least two pairs per workgroup
                 if (chunks > max_chunks)
                     chunks = max_chunks;
@@ -974,7 +977,7 @@ namespace
             if (std::is_same<P, Fast>::value && a.n_polys >= 4 && !getenv("CAT_NTT_ROWS16"))
             {
                 const u64 groups = (u64)a.n_limbs * (n1 / RM_ROWS);
-                u32 chunks = (u32)((8192 + groups - 1) / groups);
+                u32 chunks = (u32)((ROWS8_TARGET_BLOCKS + groups - 1) / groups);
                 const u32 max_chunks = (a.n_polys + 1) / 2 / 2;
                 if (chunks > max_chunks)
                     chunks = max_chunks;
