@@ -91,6 +91,35 @@ def octx_root(oracle, log_n, q):
     return r.value
 
 
+@pytest.mark.parametrize("log_n,polys", [(12, 4), (12, 5), (13, 9), (14, 6), (16, 7)])
+def test_ntt_streaming_row_pass(cat, oracle, log_n, polys):
+    """Four or more polynomials take the poly-streaming row kernels (ntt_fwd_rows8 / ntt_inv_rows8: pairs of
+    polynomials per thread, odd counts, several chunks of polynomials per row position)."""
+    n = 1 << log_n
+    primes = oracle.get_primes(2 * n, 60, 2) + oracle.get_primes(2 * n, 61, 1) + oracle.get_primes(2 * n, 49, 1)
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_NONE)
+    rng = np.random.default_rng(500 + log_n + polys)
+    ids = list(range(len(primes)))
+    x = rand_limbs(rng, primes, (polys,), n)
+    x[0, :, :3] = 0
+    x[-1, :, -1] = np.array(primes, dtype=np.uint64) - 1
+    exp = octx.ntt_forward(x, ids, lazy=False)
+    got = host(ctx.ntt_forward(dev(x), lazy=False))
+    assert (got == exp).all()
+    back = host(ctx.ntt_inverse(dev(exp), lazy=False))
+    assert (back == x).all()
+    assert (back == octx.ntt_inverse(exp, ids, lazy=False)).all()
+    # forward input range [0, 4q) and a limb subset in permuted order
+    x4 = rand_limbs(rng, primes, (polys,), n, mult=4)
+    assert (host(ctx.ntt_forward(dev(x4), lazy=False)) == octx.ntt_forward(x4, ids, lazy=False)).all()
+    sub = [2, 0, 3]
+    xs = rand_limbs(rng, [primes[i] for i in sub], (polys,), n)
+    assert (host(ctx.ntt_forward(dev(xs), limb_ids=sub)) == octx.ntt_forward(xs, sub)).all()
+    assert (host(ctx.ntt_inverse(dev(xs), limb_ids=sub)) == octx.ntt_inverse(xs, sub)).all()
+    ctx.close()
+
+
 def test_ntt_reference_known_answers(cat):
     # tests/util/ntt.cpp:77-101 through the HIP path
     g = KA["ntt_n2"]
