@@ -311,6 +311,26 @@ def test_switch_key_direct_and_rotate(cat, oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("log_n,bits,count,batch", [(12, 61, 4, 9), (13, 61, 6, 2), (12, 30, 3, 5)])
+def test_switch_key_fused_kernel_prime_sizes(cat, oracle, log_n, bits, count, batch):
+    """The fused row-pass + inner-product kernel at the prime sizes its accumulator bounds distinguish (61-bit
+    primes take the canonical-operand path), with more ciphertexts than XCD groups of 8 and every level."""
+    n = 1 << log_n
+    primes = list(reversed(oracle.get_primes(2 * n, bits, count)))
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_CKKS)
+    sk = octx.secret_key(11)
+    key = octx.relin_key(sk, 12)
+    dkey = dev(key)
+    for L in range(count - 1, 0, -1):
+        enc = np.stack([octx.uniform(L, 2, 700 + b + L) for b in range(batch)])
+        tgt = np.stack([octx.uniform(L, 1, 800 + b + L)[0] for b in range(batch)])
+        got = host(ctx.switch_key(dev(enc), dev(tgt), dkey))
+        exp = np.stack([octx.switch_key_inplace(enc[b], tgt[b], key) for b in range(batch)])
+        assert (got == exp).all(), f"switch_key L={L}"
+    ctx.close()
+
+
 def test_bfv_switch_key_rescale_and_galois_branches(cat, oracle):
     log_n = 12
     n = 1 << log_n
