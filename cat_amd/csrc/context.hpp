@@ -100,6 +100,9 @@ namespace cat
     //  - epilogue of the last pass (evaluator.cpp:2810-2816, util/rns.cpp:879-899): the transformed limb t (< 4q) is
     //      not stored; dest = (other + 4q - t) * Q^-1 mod q  [+ dest when ep_acc], with object p = b * ep_S + s
     //      addressed as base + b * *_b + s * *_s + limb * N.
+    // true when every prime the map names (first n_groups entries) is below 2^60: forward transforms then run with
+    // the wide lazy ranges (ntt.hip, policy Wide) and a first-pass-only result holds values < 16q instead of < 8q
+    bool ntt_wide(const cat_ctx *ctx, const LimbMap &map, uint32_t n_groups);
     struct NttFuse
     {
         const u64 *src = nullptr;

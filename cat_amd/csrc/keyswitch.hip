@@ -165,6 +165,7 @@ namespace
         }
     }
 
+    template <bool WIDE>
     __global__ __launch_bounds__(256, 2) void ks_rows_mac_kernel(RowsMacArgs g)
     {
         __shared__ u64 lds[RM_TW_WORDS + RM_X_WORDS];
@@ -245,7 +246,7 @@ namespace
             u64 ka[8], kb[8];
             rm_load8(ka, kp0);
             rm_load8(kb, kp1);
-            rm_rows<2>(x, tw, xs, t, q);
+            rm_rows<2, WIDE>(x, tw, xs, t, q);
             rm_below_2_62<2>(x, q);
 #pragma unroll
             for (int cidx = 0; cidx < 2; ++cidx)
@@ -279,7 +280,7 @@ namespace
 #pragma unroll
             for (int a = 0; a < 8; ++a)
                 x[0][a] = ebase[(size_t)J0 * N + a * 32];
-            rm_rows<1>(x, tw, xs, t, q);
+            rm_rows<1, WIDE>(x, tw, xs, t, q);
             rm_below_2_62<1>(x, q);
             mac(x[0], J0, x[0], J0, false);
         }
@@ -531,11 +532,14 @@ namespace cat
         }
         // step 2: modulus raise fused into the first NTT pass (ntt.hip Source): ext is written once, already
         // half transformed, instead of being written by a raise kernel and re-read
-        const bool fused_mac = log_n >= 12 && !getenv("CAT_KS_UNFUSED");
+        static const bool unfused = getenv("CAT_KS_UNFUSED") != nullptr;
+        const bool fused_mac = log_n >= 12 && !unfused;
+        bool wide = false;
         {
             LimbMap map{};
             for (u32 I = 0; I < rns; ++I)
                 map.id[I] = (unsigned char)(I == d ? k - 1 : I);
+            wide = ntt_wide(ctx, map, rns); // the same predicate launch_ntt_ex applies to this map
             NttFuse raise;
             raise.src = coeff_target;
             raise.src_stride = ckks ? (u64)d * N : (u64)target_stride;
@@ -566,7 +570,10 @@ namespace cat
             const u64 blocks = (u64)((g.groups + 7) / 8) * 8 * batch;
             if (blocks > 0x7fffffffu)
                 return fail(CAT_ERR_LOGIC, "invalid parameters");
-            hipLaunchKernelGGL(ks_rows_mac_kernel, dim3((u32)blocks), dim3(256), 0, s, g);
+            if (wide)
+                hipLaunchKernelGGL(ks_rows_mac_kernel<true>, dim3((u32)blocks), dim3(256), 0, s, g);
+            else
+                hipLaunchKernelGGL(ks_rows_mac_kernel<false>, dim3((u32)blocks), dim3(256), 0, s, g);
             CAT_HIP(hipGetLastError());
         }
         else

@@ -193,6 +193,7 @@ namespace
     // ---- arithmetic policies ----------------------------------------------------------------------------
     struct Exact
     {
+        static constexpr bool WIDE = false;
         typedef MulOp Tw;
         typedef const MulOp *Table;
         struct Mod
@@ -245,6 +246,7 @@ namespace
 
     struct Fast
     {
+        static constexpr bool WIDE = false;
         typedef MulOp3 Tw;
         struct Table
         {
@@ -324,6 +326,29 @@ namespace
         }
     };
 
+    // Fast arithmetic with wide lazy ranges, forward transforms whose primes are all below 2^60: a butterfly adds at
+    // most 4q to the range of its inputs and the split-Shoup product takes any 64-bit operand, so values may grow
+    // to 16q < 2^64 and ONE conditional subtraction of 8q every second stage replaces the per-stage guard
+    // (-2 of 18 instructions per butterfly).  Range in units of q, column pass from inputs < 4: stages 0,1,2
+    // unguarded (< 8, 12, 16), then odd stages subtract 8q first (< 8 -> < 12) and even stages do not (< 16).  Row
+    // passes accept < 16q: even local stages subtract, odd ones do not; results < 16q are brought to the usual
+    // contract (< 4q lazy, canonical otherwise) by the final reduction.
+    struct Wide : Fast
+    {
+        static constexpr bool WIDE = true;
+    };
+    // guard mode of a forward stage: 0 none, 1 subtract K = 2q (Exact) / 4q (Fast), 2 subtract 8q
+    template <class P>
+    __device__ __forceinline__ constexpr int col_guard(int global_stage)
+    {
+        return !P::WIDE ? 1 : ((global_stage & 1) && global_stage >= 3) ? 2 : 0;
+    }
+    template <class P>
+    __device__ __forceinline__ constexpr int row_guard(int local_stage)
+    {
+        return !P::WIDE ? 1 : (local_stage & 1) ? 0 : 2;
+    }
+
     // Column passes, Fast policy: the first log2(N1) <= 8 forward stages use table entries 1 .. N1-1, the last
     // log2(N1) inverse stages the entries N - N1 + 1 .. N - 1 -- at most 255 twiddles per limb, the same for every
     // column and polynomial.  A workgroup copies them to LDS (6 KB) and the butterflies read them with ds_read
@@ -349,7 +374,7 @@ namespace
 #define TW_CHUNK 8 // 4 saves ~7 VGPRs in the forward kernels but measured slower on MI355X
 #endif
     // Forward (Cooley-Tukey) local stage S: register gap 8 >> S, 2^S twiddles tw[(base << S) + g].
-    template <class P, int S>
+    template <class P, int S, int GM = 1>
     __device__ __forceinline__ void fwd_stage16(u64 (&x)[16], const typename P::Table &tw, u32 base,
                                                 const typename P::Mod &m)
     {
@@ -368,7 +393,7 @@ namespace
                 {
                     // X' = u + w*Y with u folded into the multiply chain; Y' = u - w*Y + K = 2u + K - X'
                     const int i0 = g * 2 * gap + j;
-                    const u64 u = guard(x[i0], m.K, m.negK);
+                    const u64 u = GM == 0 ? x[i0] : GM == 1 ? guard(x[i0], m.K, m.negK) : guard(x[i0], m.K << 1, m.negK << 1);
                     const u64 s = P::mul_add(x[i0 + gap], w[g - g0], m, u);
                     x[i0] = s;
                     x[i0 + gap] = shl1_add64(u, m.K) - s;
@@ -448,12 +473,12 @@ namespace
         if (K1 > 0)
         {
             in.load16(x, [&](int e) { return ((e >> (4 - K1)) * 16 + tau * SUB + (e & (SUB - 1))) * ROW_LEN + c; });
-            if (std::is_same<P, Fast>::value)
+            if (std::is_base_of<Fast, P>::value)
                 __syncthreads(); // staged twiddles visible
-            if (K1 > 0) fwd_stage16<P, 0>(x, tw, 1, m);
-            if (K1 > 1) fwd_stage16<P, 1>(x, tw, 1, m);
-            if (K1 > 2) fwd_stage16<P, 2>(x, tw, 1, m);
-            if (K1 > 3) fwd_stage16<P, 3>(x, tw, 1, m);
+            if (K1 > 0) fwd_stage16<P, 0, col_guard<P>(0)>(x, tw, 1, m);
+            if (K1 > 1) fwd_stage16<P, 1, col_guard<P>(1)>(x, tw, 1, m);
+            if (K1 > 2) fwd_stage16<P, 2, col_guard<P>(2)>(x, tw, 1, m);
+            if (K1 > 3) fwd_stage16<P, 3, col_guard<P>(3)>(x, tw, 1, m);
 #pragma unroll
             for (int e = 0; e < 16; ++e)
             {
@@ -468,14 +493,14 @@ namespace
         else
         {
             in.load16(x, [&](int l) { return (tau * 16 + l) * ROW_LEN + c; });
-            if (std::is_same<P, Fast>::value)
+            if (std::is_base_of<Fast, P>::value)
                 __syncthreads();
         }
         const u32 base = (1u << K1) + tau;
-        fwd_stage16<P, 0>(x, tw, base, m);
-        fwd_stage16<P, 1>(x, tw, base, m);
-        fwd_stage16<P, 2>(x, tw, base, m);
-        fwd_stage16<P, 3>(x, tw, base, m);
+        fwd_stage16<P, 0, col_guard<P>(K1 + 0)>(x, tw, base, m);
+        fwd_stage16<P, 1, col_guard<P>(K1 + 1)>(x, tw, base, m);
+        fwd_stage16<P, 2, col_guard<P>(K1 + 2)>(x, tw, base, m);
+        fwd_stage16<P, 3, col_guard<P>(K1 + 3)>(x, tw, base, m);
 #pragma unroll
         for (int l = 0; l < 16; ++l)
             p[(tau * 16 + l) * ROW_LEN + c] = x[l];
@@ -502,10 +527,10 @@ namespace
         for (int h = 0; h < 16; ++h)
             x[h] = p[h * 16 + t];
         const u32 base1 = n1 + row;
-        fwd_stage16<P, 0>(x, tw, base1, m);
-        fwd_stage16<P, 1>(x, tw, base1, m);
-        fwd_stage16<P, 2>(x, tw, base1, m);
-        fwd_stage16<P, 3>(x, tw, base1, m);
+        fwd_stage16<P, 0, row_guard<P>(0)>(x, tw, base1, m);
+        fwd_stage16<P, 1, row_guard<P>(1)>(x, tw, base1, m);
+        fwd_stage16<P, 2, row_guard<P>(2)>(x, tw, base1, m);
+        fwd_stage16<P, 3, row_guard<P>(3)>(x, tw, base1, m);
 #pragma unroll
         for (int h = 0; h < 16; ++h)
             s[h * 17 + t] = x[h];
@@ -514,13 +539,13 @@ namespace
         for (int l = 0; l < 16; ++l)
             x[l] = s[t * 17 + l];
         const u32 base2 = base1 * 16 + t;
-        fwd_stage16<P, 0>(x, tw, base2, m);
-        fwd_stage16<P, 1>(x, tw, base2, m);
-        fwd_stage16<P, 2>(x, tw, base2, m);
-        fwd_stage16<P, 3>(x, tw, base2, m);
+        fwd_stage16<P, 0, row_guard<P>(4)>(x, tw, base2, m);
+        fwd_stage16<P, 1, row_guard<P>(5)>(x, tw, base2, m);
+        fwd_stage16<P, 2, row_guard<P>(6)>(x, tw, base2, m);
+        fwd_stage16<P, 3, row_guard<P>(7)>(x, tw, base2, m);
 #pragma unroll
         for (int l = 0; l < 16; ++l)
-            x[l] = P::finish_fwd(x[l], m, a.lazy != 0);
+            x[l] = P::finish_fwd(P::WIDE ? guard(x[l], m.K << 1, m.negK << 1) : x[l], m, a.lazy != 0);
         wave_lds_sync();
 #pragma unroll
         for (int l = 0; l < 16; ++l)
@@ -564,6 +589,7 @@ namespace
                 x[n][a] = src[n][a * 32];
     }
 
+    template <bool WIDE>
     __global__ __launch_bounds__(256, 2) void ntt_fwd_rows8(NttArgs a, u32 chunks)
     {
         __shared__ u64 lds[RM_TW_WORDS + RM_X_WORDS];
@@ -608,7 +634,7 @@ namespace
                                      base + (u64)(2 * nx + 1 < a.n_polys ? 2 * nx + 1 : 2 * nx) * a.poly_stride + t};
                 rows8_load<2>(xn, src);
             }
-            rm_rows<2>(x, tw, xs, t, q);
+            rm_rows<2, WIDE>(x, tw, xs, t, q);
             const bool two = 2 * pi + 1 < a.n_polys;
             // third exchange: from 8 consecutive coefficients per thread to 16-byte pieces that are consecutive
             // across the lanes of a row, so that every store instruction writes whole 512-byte runs
@@ -789,7 +815,7 @@ namespace
 #pragma unroll
         for (int l = 0; l < 16; ++l)
             x[l] = p[(tau * 16 + l) * ROW_LEN + c];
-        if (std::is_same<P, Fast>::value)
+        if (std::is_base_of<Fast, P>::value)
             __syncthreads(); // staged twiddles visible
         // global stages 8..11
         inv_stage16<P, 0>(x, tw, n - (n >> 8) + 1 + tau * 8, m);
@@ -917,7 +943,8 @@ namespace
         if (fwd)
             hipLaunchKernelGGL((ntt_fwd_cols<P, LOGN1>), dim3(blocks), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL((ntt_inv_cols<P, LOGN1>), dim3(blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((ntt_inv_cols<typename std::conditional<P::WIDE, Fast, P>::type, LOGN1>), dim3(blocks),
+                               dim3(256), 0, s, a);
     }
 
     template <class P>
@@ -929,10 +956,11 @@ namespace
             if (n_lp > 0x7fffffffu)
                 return cat::fail(CAT_ERR_LOGIC, "invalid parameters");
             const u32 threads = ctx->n / 2 >= 256 ? 256 : 64;
+            typedef typename std::conditional<P::WIDE, Fast, P>::type Q;
             if (forward)
-                hipLaunchKernelGGL((ntt_small<P, true>), dim3((u32)n_lp), dim3(threads), 0, s, a);
+                hipLaunchKernelGGL((ntt_small<Q, true>), dim3((u32)n_lp), dim3(threads), 0, s, a);
             else
-                hipLaunchKernelGGL((ntt_small<P, false>), dim3((u32)n_lp), dim3(threads), 0, s, a);
+                hipLaunchKernelGGL((ntt_small<Q, false>), dim3((u32)n_lp), dim3(threads), 0, s, a);
             CAT_HIP(hipGetLastError());
             return CAT_OK;
         }
@@ -957,7 +985,7 @@ namespace
             cols();
             if (first_only)
                 ;
-            else if (std::is_same<P, Fast>::value && !a.ep_dest && a.n_polys >= 4 && !getenv("CAT_NTT_ROWS16"))
+            else if (std::is_base_of<Fast, P>::value && !a.ep_dest && a.n_polys >= 4 && !getenv("CAT_NTT_ROWS16"))
             {
                 // poly-streaming row pass: workgroups = limbs x 8-row positions x chunks of the polynomials
                 const u64 groups = (u64)a.n_limbs * (n1 / RM_ROWS);
@@ -967,14 +995,14 @@ namespace
                     chunks = max_chunks;
                 if (chunks < 1)
                     chunks = 1;
-                hipLaunchKernelGGL(ntt_fwd_rows8, dim3((u32)(groups * chunks)), dim3(256), 0, s, a, chunks);
+                hipLaunchKernelGGL(ntt_fwd_rows8<P::WIDE>, dim3((u32)(groups * chunks)), dim3(256), 0, s, a, chunks);
             }
             else
                 hipLaunchKernelGGL((ntt_fwd_rows<P>), dim3((u32)row_blocks), dim3(256), 0, s, a);
         }
         else
         {
-            if (std::is_same<P, Fast>::value && a.n_polys >= 4 && !getenv("CAT_NTT_ROWS16"))
+            if (std::is_base_of<Fast, P>::value && a.n_polys >= 4 && !getenv("CAT_NTT_ROWS16"))
             {
                 const u64 groups = (u64)a.n_limbs * (n1 / RM_ROWS);
                 u32 chunks = (u32)((ROWS8_TARGET_BLOCKS + groups - 1) / groups);
@@ -986,7 +1014,8 @@ namespace
                 hipLaunchKernelGGL(ntt_inv_rows8, dim3((u32)(groups * chunks)), dim3(256), 0, s, a, chunks);
             }
             else
-                hipLaunchKernelGGL((ntt_inv_rows<P>), dim3((u32)row_blocks), dim3(256), 0, s, a);
+                hipLaunchKernelGGL((ntt_inv_rows<typename std::conditional<P::WIDE, Fast, P>::type>),
+                                   dim3((u32)row_blocks), dim3(256), 0, s, a);
             cols();
         }
         CAT_HIP(hipGetLastError());
@@ -996,6 +1025,17 @@ namespace
 
 namespace cat
 {
+    bool ntt_wide(const cat_ctx *ctx, const LimbMap &map, uint32_t n_groups)
+    {
+        static const bool off = getenv("CAT_NTT_NARROW") != nullptr;
+        if (off)
+            return false;
+        for (uint32_t i = 0; i < n_groups; ++i)
+            if (ctx->hmods[map.id[i]].q >> 60)
+                return false;
+        return true;
+    }
+
     cat_status launch_ntt(cat_ctx *ctx, bool forward, u64 *d_data, const LimbMap &map, uint32_t n_limbs,
                           uint32_t n_polys, bool lazy, hipStream_t s, bool exact)
     {
@@ -1057,6 +1097,8 @@ namespace cat
             return launch_policy<Exact>(ctx, forward, a, s, false);
         }
         a.tw = forward ? (const void *)ctx->d_tw3_fwd : (const void *)ctx->d_tw3_inv;
+        if (forward && ctx->log_n >= 12 && ntt_wide(ctx, map, (n_limbs + limb_group - 1) / limb_group))
+            return launch_policy<Wide>(ctx, forward, a, s, fuse && fuse->first_pass_only);
         return launch_policy<Fast>(ctx, forward, a, s, fuse && fuse->first_pass_only);
     }
 } // namespace cat

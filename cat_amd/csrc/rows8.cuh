@@ -42,7 +42,8 @@ namespace
     }
 
     // one radix-2 stage over the 8 registers of ND digits: CNT twiddles, register gap 4 / CNT
-    template <int ND, int CNT>
+    // GM: guard of the additive operand: 0 none, 1 subtract K = 4q, 2 subtract 8q (wide ranges, ntt.hip policy Wide)
+    template <int ND, int CNT, int GM = 1>
     __device__ __forceinline__ void rm_stage(u64 (&x)[ND][8], const u64 *tw, u32 entry, u64 K, u64 negK, u64 nq)
     {
         constexpr int gap = 4 / CNT;
@@ -64,7 +65,7 @@ namespace
                 for (int n = 0; n < ND; ++n)
                 {
                     const int i0 = g * 2 * gap + j;
-                    const u64 u = rm_guard(x[n][i0], K, negK);
+                    const u64 u = GM == 0 ? x[n][i0] : GM == 1 ? rm_guard(x[n][i0], K, negK) : rm_guard(x[n][i0], K << 1, negK << 1);
                     const u64 v = mul_split_add(x[n][i0 + gap], w[g], nq, u);
                     x[n][i0] = v;
                     x[n][i0 + gap] = shl1_add64(u, K) - v;
@@ -80,13 +81,14 @@ namespace
     }
 
     // last 8 stages of ND limb-rows held as x[n][a] = row[a * 32 + t]; result x[n][u] = row[8 t + u], values < 4q
-    template <int ND>
+    // WIDE: inputs < 16q, a subtraction of 8q before the even stages only (primes below 2^60)
+    template <int ND, bool WIDE = false>
     __device__ __forceinline__ void rm_rows(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q)
     {
         const u64 K = q << 2, negK = 0 - K, nq = 0 - q;
-        rm_stage<ND, 1>(x, tw, 0, K, negK, nq);
-        rm_stage<ND, 2>(x, tw, 1, K, negK, nq);
-        rm_stage<ND, 4>(x, tw, 3, K, negK, nq);
+        rm_stage<ND, 1, WIDE ? 2 : 1>(x, tw, 0, K, negK, nq);
+        rm_stage<ND, 2, WIDE ? 0 : 1>(x, tw, 1, K, negK, nq);
+        rm_stage<ND, 4, WIDE ? 2 : 1>(x, tw, 3, K, negK, nq);
         const u32 A = t >> 2, c = t & 3;
 #pragma unroll
         for (int n = 0; n < ND; ++n)
@@ -100,9 +102,9 @@ namespace
             for (int b = 0; b < 8; ++b)
                 x[n][b] = xs[(A << 5) | ((b ^ A) << 2) | c]; // element A*32 + 4b + c
         }
-        rm_stage<ND, 1>(x, tw, 7 + A, K, negK, nq);
-        rm_stage<ND, 2>(x, tw, 15 + 2 * A, K, negK, nq);
-        rm_stage<ND, 4>(x, tw, 31 + 4 * A, K, negK, nq);
+        rm_stage<ND, 1, WIDE ? 0 : 1>(x, tw, 7 + A, K, negK, nq);
+        rm_stage<ND, 2, WIDE ? 2 : 1>(x, tw, 15 + 2 * A, K, negK, nq);
+        rm_stage<ND, 4, WIDE ? 0 : 1>(x, tw, 31 + 4 * A, K, negK, nq);
         const u32 bh = t & 3; // reader t = A*4 + b_hi holds elements 8t + u
 #pragma unroll
         for (int n = 0; n < ND; ++n)
@@ -116,13 +118,13 @@ namespace
             for (int u = 0; u < 8; ++u)
                 x[n][u] = xs[(u << 5) | (A << 2) | (bh ^ (u & 3))];
         }
-        rm_stage<ND, 2>(x, tw, 63 + 2 * t, K, negK, nq);
-        rm_stage<ND, 4>(x, tw, 127 + 4 * t, K, negK, nq);
+        rm_stage<ND, 2, WIDE ? 2 : 1>(x, tw, 63 + 2 * t, K, negK, nq);
+        rm_stage<ND, 4, WIDE ? 0 : 1>(x, tw, 127 + 4 * t, K, negK, nq);
 #pragma unroll
         for (int n = 0; n < ND; ++n)
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                x[n][u] = rm_guard(x[n][u], K, negK);
+                x[n][u] = rm_guard(WIDE ? rm_guard(x[n][u], K << 1, negK << 1) : x[n][u], K, negK);
     }
 
 
