@@ -91,12 +91,14 @@ def octx_root(oracle, log_n, q):
     return r.value
 
 
+@pytest.mark.parametrize("big", [61, 59])
 @pytest.mark.parametrize("log_n,polys", [(12, 4), (12, 5), (13, 9), (14, 6), (16, 7)])
-def test_ntt_streaming_row_pass(cat, oracle, log_n, polys):
+def test_ntt_streaming_row_pass(cat, oracle, log_n, polys, big):
     """Four or more polynomials take the poly-streaming row kernels (ntt_fwd_rows8 / ntt_inv_rows8: pairs of
-    polynomials per thread, odd counts, several chunks of polynomials per row position)."""
+    polynomials per thread, odd counts, several chunks of polynomials per row position).  With a 61-bit prime in
+    the set the forward transform keeps values below 8q; with all primes below 2^60 it takes the wide-range path."""
     n = 1 << log_n
-    primes = oracle.get_primes(2 * n, 60, 2) + oracle.get_primes(2 * n, 61, 1) + oracle.get_primes(2 * n, 49, 1)
+    primes = oracle.get_primes(2 * n, 60, 2) + oracle.get_primes(2 * n, big, 1) + oracle.get_primes(2 * n, 49, 1)
     octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
     ctx = cat.Context(log_n, primes, cat.SCHEME_NONE)
     rng = np.random.default_rng(500 + log_n + polys)
