@@ -264,7 +264,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel": "batched forward NTT = ntt_fwd_cols<Fast,8> + ntt_fwd_rows8 (two launches per transform; `achieved` counts the transform's algorithmic bytes once over the pair's time)",
+            "kernel": "batched forward NTT = ntt_fwd_cols<Wide,8> + ntt_fwd_rows8<true> (two launches per transform; `achieved` counts the transform's algorithmic bytes once over the pair's time)",
             "workload": f"N=65536, {args.ntt_limbs} x 60-bit primes, {P} polys ({coeffs * 8 / 1e9:.2f} GB), in place",
             "algorithmic_bytes_per_launch_pair": alg_bytes,
             "forward_ms": f_ms,
@@ -279,6 +279,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()  # rank 0 may still be in its roofline leg
         dist.destroy_process_group()
 
 
