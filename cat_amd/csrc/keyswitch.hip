@@ -523,9 +523,22 @@ namespace cat
         const u64 *coeff_target = target;
         if (ckks)
         {
-            CAT_HIP(hipMemcpy2DAsync(t_target, d * N * sizeof(u64), target, target_stride * sizeof(u64),
-                                     d * N * sizeof(u64), batch, hipMemcpyDeviceToDevice, s));
-            cat_status st = launch_ntt(ctx, false, t_target, ident, d, batch, false, s);
+            cat_status st;
+            if (log_n >= 12)
+            {
+                // out of place: the first inverse pass reads the target where it lies (it stays in NTT form for the
+                // I == J terms) and writes t_target
+                NttFuse in;
+                in.src = target;
+                in.src_stride = target_stride;
+                st = launch_ntt_ex(ctx, false, t_target, ident, d, batch, false, (u64)d * N, 1, false, s, false, &in);
+            }
+            else
+            {
+                CAT_HIP(hipMemcpy2DAsync(t_target, d * N * sizeof(u64), target, target_stride * sizeof(u64),
+                                         d * N * sizeof(u64), batch, hipMemcpyDeviceToDevice, s));
+                st = launch_ntt(ctx, false, t_target, ident, d, batch, false, s);
+            }
             if (st != CAT_OK)
                 return st;
             coeff_target = t_target;

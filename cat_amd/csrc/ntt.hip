@@ -687,6 +687,9 @@ namespace
         const u64 *tw = lds + rl * 256;
         u64 *xs = lds + RM_TW_WORDS + rl * 256;
         u64 *base = a.data + ((u64)limb << a.log_n) + (size_t)(tile * RM_ROWS + rl) * 256;
+        // out-of-place form (NttFuse::src on an inverse transform): the rows come from another buffer of the same
+        // limb layout, objects src_stride apart
+        const u64 *in_base = a.src + ((u64)limb << a.log_n) + (size_t)(tile * RM_ROWS + rl) * 256;
 
         // loads: 16-byte pieces consecutive across the lanes of a row, turned into 8 consecutive coefficients per
         // thread through LDS (element e at e ^ ((e >> 5) & 7), as in the forward kernel's store side)
@@ -694,7 +697,8 @@ namespace
 #pragma unroll
             for (int n = 0; n < 2; ++n)
             {
-                const u64 *src = base + (u64)(2 * pi + n < a.n_polys ? 2 * pi + n : 2 * pi) * a.poly_stride;
+                const u32 poly = 2 * pi + n < a.n_polys ? 2 * pi + n : 2 * pi;
+                const u64 *src = a.src ? in_base + (u64)poly * a.src_stride : base + (u64)poly * a.poly_stride;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     raw[n][i] = *reinterpret_cast<const ulonglong2 *>(src + (i * 32 + t) * 2);
@@ -760,9 +764,10 @@ namespace
         u64 *s = lds + r * ROW_PITCH;
 
         u64 x[16];
+        const u64 *pin = a.src ? a.src + (u64)w.poly * a.src_stride + ((u64)w.limb << a.log_n) + (size_t)row * ROW_LEN : p;
 #pragma unroll
         for (int h = 0; h < 16; ++h)
-            s[h * 17 + t] = p[h * 16 + t];
+            s[h * 17 + t] = pin[h * 16 + t];
         wave_lds_sync();
 #pragma unroll
         for (int l = 0; l < 16; ++l)
@@ -1073,7 +1078,10 @@ namespace cat
         a.kdim = ctx->k;
         if (fuse)
         {
-            if (!forward || (fuse->ep_dest && (ctx->log_n < 12 || !lazy)) ||
+            // inverse transforms take only the out-of-place source (src_kind 0, N >= 4096, one modulus per limb)
+            if ((!forward && (fuse->ep_dest || fuse->first_pass_only || fuse->src_kind != 0 || ctx->log_n < 12 ||
+                              limb_group != 1)) ||
+                (fuse->ep_dest && (ctx->log_n < 12 || !lazy)) ||
                 (fuse->first_pass_only && (ctx->log_n < 12 || exact || fuse->ep_dest)))
                 return fail(CAT_ERR_LOGIC, "unsupported fused transform");
             a.src = fuse->src;
