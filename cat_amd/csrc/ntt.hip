@@ -126,10 +126,11 @@ namespace
         u64 half, fix;
         int mode;        // 0 plain, 1 reduce modulo q, 2 round-and-fix
         bool reduce2;
+        bool close;      // mode 1: the source prime is below 2q, one conditional subtraction reduces
         __device__ __forceinline__ u64 derive(u64 v) const
         {
             if (mode == 1)
-                v = barrett64(v, q, ratio1);
+                v = close ? guard(v, q, 0 - q) : barrett64(v, q, ratio1);
             else if (mode == 2)
             {
                 v = barrett64(v + half, Q, Qratio1);
@@ -162,6 +163,7 @@ namespace
         Source s;
         s.q = s.ratio1 = s.Q = s.Qratio1 = s.half = s.fix = 0;
         s.reduce2 = false;
+        s.close = false;
         if (!a.src)
         {
             s.p = a.data + w.offset + extra;
@@ -174,7 +176,9 @@ namespace
         if (a.src_kind == 0)
         {
             s.p = a.src + w.src_offset + extra;
-            s.mode = a.mods[w.src_mod].q > m.q ? 1 : 0; // copy when q_J <= q_I (evaluator.cpp:2643)
+            const u64 qs = a.mods[w.src_mod].q;
+            s.mode = qs > m.q ? 1 : 0; // copy when q_J <= q_I (evaluator.cpp:2643)
+            s.close = qs < (m.q << 1);
         }
         else
         {
@@ -952,6 +956,12 @@ namespace
                                dim3(256), 0, s, a);
     }
 
+    bool rows16_forced()
+    {
+        static const bool on = getenv("CAT_NTT_ROWS16") != nullptr; // A/B switch: 16-per-thread row kernels everywhere
+        return on;
+    }
+
     template <class P>
     cat_status launch_policy(cat_ctx *ctx, bool forward, NttArgs &a, hipStream_t s, bool first_only)
     {
@@ -990,7 +1000,7 @@ namespace
             cols();
             if (first_only)
                 ;
-            else if (std::is_base_of<Fast, P>::value && !a.ep_dest && a.n_polys >= 4 && !getenv("CAT_NTT_ROWS16"))
+            else if (std::is_base_of<Fast, P>::value && !a.ep_dest && a.n_polys >= 4 && !rows16_forced())
             {
                 // poly-streaming row pass: workgroups = limbs x 8-row positions x chunks of the polynomials
                 const u64 groups = (u64)a.n_limbs * (n1 / RM_ROWS);
@@ -1007,7 +1017,7 @@ namespace
         }
         else
         {
-            if (std::is_base_of<Fast, P>::value && a.n_polys >= 4 && !getenv("CAT_NTT_ROWS16"))
+            if (std::is_base_of<Fast, P>::value && a.n_polys >= 4 && !rows16_forced())
             {
                 const u64 groups = (u64)a.n_limbs * (n1 / RM_ROWS);
                 u32 chunks = (u32)((ROWS8_TARGET_BLOCKS + groups - 1) / groups);
