@@ -58,10 +58,25 @@ namespace
         {
             const DevMod m = g.mods[g.omap.id[o]];
             const u64 *row = g.matrix + (u64)o * g.isz;
-            u64 lo = 0, hi = 0;
-            for (u32 j = 0; j < g.isz; ++j)
-                mac128(lo, hi, stage[j * 256 + threadIdx.x], row[j]);
-            dst[(u64)(g.out_off + o) << g.log_n] = barrett128(lo, hi, m.q, m.ratio0, m.ratio1);
+            // scaled residues and matrix entries are canonical modulo primes of at most 61 bits: rm_mac's bounds
+            Acc acc;
+            acc.lo = acc.hi = 0;
+            acc.cc = 0;
+            u32 j = 0;
+            for (; j + 2 <= g.isz; j += 2)
+            {
+                u64 mid = 0;
+                rm_mac(acc, mid, stage[j * 256 + threadIdx.x], row[j]);
+                rm_mac(acc, mid, stage[(j + 1) * 256 + threadIdx.x], row[j + 1]);
+                rm_fold(acc, mid);
+            }
+            if (j < g.isz)
+            {
+                u64 mid = 0;
+                rm_mac(acc, mid, stage[j * 256 + threadIdx.x], row[j]);
+                rm_fold(acc, mid);
+            }
+            dst[(u64)(g.out_off + o) << g.log_n] = barrett128(acc.lo, acc.hi + acc.cc, m.q, m.ratio0, m.ratio1);
         }
         if (g.mt_matrix)
         {

@@ -744,7 +744,7 @@ cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, co
     // perm = [batch][2][L][N] permuted copy of the ciphertexts; c0 <- perm(c0), c1 <- 0 and the key switch reads its
     // target perm(c1) in place, one ciphertext stride apart (:2410-2449).  The permuted copy must survive
     // launch_switch_key's own workspace use, so it is carved from the same block, after the key-switch region.
-    const size_t N = ctx->n, ctw = (size_t)2 * L * N, lw = (size_t)L * N * sizeof(u64);
+    const size_t N = ctx->n, ctw = (size_t)2 * L * N;
     const size_t ks_words = (size_t)batch * ((size_t)L + (size_t)(L + 1) * L + 2 * (L + 1) + 2 * L) * N;
     u64 *ws = (u64 *)workspace(ctx, (ks_words + (size_t)batch * ctw) * sizeof(u64));
     if (!ws)
@@ -755,9 +755,9 @@ cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, co
     st = launch_galois(ctx, ntt, (const u64 *)ct, perm, elt, ctx->identity_map(), L, batch * 2, (hipStream_t)s);
     if (st != CAT_OK)
         return st;
-    CAT_HIP(hipMemcpy2DAsync(ct, ctw * sizeof(u64), perm, ctw * sizeof(u64), lw, batch, hipMemcpyDeviceToDevice,
-                             (hipStream_t)s));
-    CAT_HIP(hipMemset2DAsync((u64 *)ct + (size_t)L * N, ctw * sizeof(u64), 0, lw, batch, (hipStream_t)s));
+    st = launch_copy_c0_zero_c1(ctx, perm, (u64 *)ct, L, batch, (hipStream_t)s);
+    if (st != CAT_OK)
+        return st;
     return launch_switch_key(ctx, (u64 *)ct, tgt, (const u64 *)key, L, batch, ctw, ctw, (hipStream_t)s);
 }
 

@@ -135,6 +135,8 @@ namespace cat
     cat_status launch_galois(cat_ctx *ctx, bool ntt_domain, const u64 *in, u64 *out, uint32_t elt, const LimbMap &map,
                              uint32_t n_limbs, uint32_t n_polys, hipStream_t s);
     cat_status launch_drop_limb(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t n_polys, hipStream_t s);
+    // out[b][0] = in[b][0], out[b][1] = 0 for `batch` size-2 ciphertexts of L limbs
+    cat_status launch_copy_c0_zero_c1(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t batch, hipStream_t s);
     // enc_stride / target_stride: words between consecutive ciphertexts / targets of the batch
     cat_status launch_switch_key(cat_ctx *ctx, u64 *enc, const u64 *target, const u64 *key, uint32_t L, uint32_t batch,
                                  size_t enc_stride, size_t target_stride, hipStream_t s);

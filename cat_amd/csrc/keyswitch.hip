@@ -123,37 +123,6 @@ namespace
         u32 groups;        // (d+1) * N / 2048
     };
 
-    // 128-bit lazy accumulation without a 64x64 high product.  With a = a1 2^32 + a0 < 2^62 and b < 2^60 (the range
-    // guard in rm_rows and canonical key words):  a b = a0 b0 + (a0 b1 + a1 b0) 2^32 + a1 b1 2^64, where
-    //   lo  += a0 b0        one v_mad_u64_u32, its carry-out counted in `cc` (weight 2^64),
-    //   mid += a0 b1 + a1 b0   < 2^62.4 per term: two terms fit 64 bits, folded into lo/hi by fold(),
-    //   hi  += a1 b1        < 2^58 per term, no carry for up to 64 terms.
-    struct Acc
-    {
-        u64 lo, hi;
-        u32 cc;
-    };
-    __device__ __forceinline__ void rm_mac(Acc &acc, u64 &mid, u64 a, u64 b)
-    {
-        const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-        u64 carry;
-        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc.lo), "=s"(carry) : "v"(a0), "v"(b0));
-        asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(acc.cc) : "s"(carry) : "vcc");
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc.hi) : "v"(a1), "v"(b1) : "vcc");
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
-            "v_mad_u64_u32 %0, vcc, %3, %4, %0"
-            : "+v"(mid)
-            : "v"(a0), "v"(b1), "v"(a1), "v"(b0)
-            : "vcc");
-    }
-    __device__ __forceinline__ void rm_fold(Acc &acc, u64 mid)
-    {
-        const u64 t = acc.lo + (mid << 32);
-        acc.cc += t < acc.lo;
-        acc.lo = t;
-        acc.hi += mid >> 32;
-    }
-
     __device__ __forceinline__ void rm_load8(u64 (&v)[8], const u64 *p)
     {
 #pragma unroll

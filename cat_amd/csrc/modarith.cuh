@@ -199,6 +199,38 @@ __device__ __forceinline__ u64 mul_split_add(u64 x, const MulOp3 &w, u64 nq, u64
     return mul_split_add(x, w.w0, w.w1, w.q0, w.q1, nq, a);
 }
 
+// 128-bit lazy accumulation without a 64x64 high product.  a b = a0 b0 + (a0 b1 + a1 b0) 2^32 + a1 b1 2^64 with
+//   lo  += a0 b0            one v_mad_u64_u32, its carry-out counted in `cc` (weight 2^64),
+//   mid += a0 b1 + a1 b0    summed over at most TWO terms, then folded into lo/hi by rm_fold(),
+//   hi  += a1 b1            plain 64-bit accumulation.
+// Operand bounds the callers keep: (a < 2^62, b < 2^60) or (a, b < 2^61); then a term's middle sum is below 2^63,
+// so two terms fit 64 bits, and a1 b1 < 2^58, so up to 64 terms need no carry.
+struct Acc
+{
+    u64 lo, hi;
+    u32 cc;
+};
+__device__ __forceinline__ void rm_mac(Acc &acc, u64 &mid, u64 a, u64 b)
+{
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc.lo), "=s"(carry) : "v"(a0), "v"(b0));
+    asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(acc.cc) : "s"(carry) : "vcc");
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc.hi) : "v"(a1), "v"(b1) : "vcc");
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, %4, %0"
+        : "+v"(mid)
+        : "v"(a0), "v"(b1), "v"(a1), "v"(b0)
+        : "vcc");
+}
+__device__ __forceinline__ void rm_fold(Acc &acc, u64 mid)
+{
+    const u64 t = acc.lo + (mid << 32);
+    acc.cc += t < acc.lo;
+    acc.lo = t;
+    acc.hi += mid >> 32;
+}
+
 // Per-modulus constants of the NTT kernels (both arithmetic flavours)
 struct __attribute__((aligned(16))) NttMod
 {

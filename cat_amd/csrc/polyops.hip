@@ -262,6 +262,22 @@ namespace
         }
     }
 
+    // apply_galois_inplace (evaluator.cpp:2410-2449): out[b][0] = in[b][0], out[b][1] = 0 for ciphertexts of 2 x words2
+    // 16-byte pieces each, in one pass
+    __global__ __launch_bounds__(256) void copy_c0_zero_c1_kernel(const u64 *in, u64 *out, u64 words2, u64 total2)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += stride)
+        {
+            const u64 b = i / words2, off = i - b * words2;
+            const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(in)[b * 2 * words2 + off];
+            ulonglong2 z;
+            z.x = z.y = 0;
+            reinterpret_cast<ulonglong2 *>(out)[b * 2 * words2 + off] = v;
+            reinterpret_cast<ulonglong2 *>(out)[(b * 2 + 1) * words2 + off] = z;
+        }
+    }
+
     u32 grid_for(u64 items)
     {
         u64 blocks = (items + 255) / 256;
@@ -424,6 +440,16 @@ namespace cat
             hipLaunchKernelGGL(galois_ntt_kernel, dim3(grid_for(g.total)), dim3(256), 0, s, g);
         else
             hipLaunchKernelGGL(galois_coeff_kernel, dim3(grid_for(g.total)), dim3(256), 0, s, g);
+        CAT_HIP(hipGetLastError());
+        return CAT_OK;
+    }
+
+    cat_status launch_copy_c0_zero_c1(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t batch, hipStream_t s)
+    {
+        const u64 words2 = ((u64)L << ctx->log_n) >> 1, total2 = words2 * batch;
+        if (total2 == 0)
+            return CAT_OK;
+        hipLaunchKernelGGL(copy_c0_zero_c1_kernel, dim3(grid_for(total2)), dim3(256), 0, s, in, out, words2, total2);
         CAT_HIP(hipGetLastError());
         return CAT_OK;
     }
