@@ -120,7 +120,10 @@ def config5(steps):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--only", type=int, default=0, help="run one configuration (3, 4 or 5)")
     a = ap.parse_args()
     for f in (config3, config4, config5):
+        if a.only and f.__name__ != f"config{a.only}":
+            continue
         print(json.dumps(f(a.steps)), flush=True)
         torch.cuda.empty_cache()
