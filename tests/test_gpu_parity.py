@@ -333,6 +333,31 @@ def test_switch_key_fused_kernel_prime_sizes(cat, oracle, log_n, bits, count, ba
     ctx.close()
 
 
+@pytest.mark.parametrize("bits", [60, 61])
+def test_switch_key_extreme_operands(cat, oracle, bits):
+    """Largest operands the lazy accumulators of the fused key-switch kernel can meet: every key word and every
+    target coefficient equal to q - 1 (and 0 / alternating patterns), at the largest prime sizes."""
+    log_n = 12
+    n = 1 << log_n
+    primes = list(reversed(oracle.get_primes(2 * n, bits, 8)))
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_CKKS)
+    k = len(primes)
+    L = k - 1
+    qs = np.array(primes, dtype=np.uint64)
+    key = np.broadcast_to((qs - 1)[None, None, :, None], (k - 1, 2, k, n)).copy()
+    enc = np.stack([octx.uniform(L, 2, 900 + b) for b in range(3)])
+    tgt = np.empty((3, L, n), dtype=np.uint64)
+    tgt[0] = (qs[:L] - 1)[:, None]
+    tgt[1] = 0
+    tgt[2] = (qs[:L] - 1)[:, None]
+    tgt[2, :, ::2] = 1
+    got = host(ctx.switch_key(dev(enc), dev(tgt), dev(key)))
+    exp = np.stack([octx.switch_key_inplace(enc[b], tgt[b], key) for b in range(3)])
+    assert (got == exp).all()
+    ctx.close()
+
+
 def test_bfv_switch_key_rescale_and_galois_branches(cat, oracle):
     log_n = 12
     n = 1 << log_n
