@@ -849,6 +849,7 @@ struct so_rnstool
     so_mulmod_op neg_inv_prod_q_mod_m_tilde;
     uint64_t *prod_q_mod_Bsk;
     so_mulmod_op *inv_q_last_mod_q;
+    uint64_t inv_q_last_mod_t; /* rns.cpp:778-786, BGV */
     so_ntt_tables **Bsk_tables;
     int log_n;
 };
@@ -946,6 +947,10 @@ static so_rnstool *rnstool_create_ex(size_t n, const uint64_t *q, size_t q_size,
             so_mulmod_op_set(&r->inv_q_last_mod_q[i], temp, &r->base_q->base[i]);
         }
     }
+    /* rns.cpp:778-786 */
+    r->inv_q_last_mod_t = 1;
+    if (t != 0)
+        so_try_invert_uint_mod(q[q_size - 1], t, &r->inv_q_last_mod_t);
     return r;
 }
 
@@ -1028,6 +1033,38 @@ void so_divide_and_round_q_last_inplace(const so_rnstool *r, uint64_t *input)
         mul_poly_op(input + i * n, n, r->inv_q_last_mod_q[i], m, input + i * n);
     }
     free(temp);
+}
+
+/* util/rns.cpp:1203-1246 (BGV / NTT domain) */
+void so_mod_t_and_divide_q_last_ntt_inplace(const so_rnstool *r, uint64_t *input, so_ntt_tables *const *tables)
+{
+    size_t L = r->base_q->size, n = r->n;
+    const so_modulus *lm = &r->base_q->base[L - 1];
+    uint64_t *c_last = input + (L - 1) * n;
+    uint64_t *neg = (uint64_t *)malloc(sizeof(uint64_t) * n), *delta = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    so_ntt_inverse(c_last, tables[L - 1], 0);
+    so_modulo_poly_coeffs(c_last, n, &r->t, neg);
+    so_negate_poly_coeffmod(neg, n, &r->t, neg);
+    if (r->inv_q_last_mod_t != 1)
+        so_multiply_poly_scalar_coeffmod(neg, n, r->inv_q_last_mod_t, &r->t, neg);
+    for (size_t i = 0; i + 1 < L; i++)
+    {
+        const so_modulus *m = &r->base_q->base[i];
+        so_modulo_poly_coeffs(neg, n, m, delta);
+        so_multiply_poly_scalar_coeffmod(delta, n, lm->value, m, delta);
+        for (size_t k = 0; k < n; k++)
+            delta[k] = so_add_uint_mod(delta[k], so_barrett_reduce_64(c_last[k], m), m);
+        so_ntt_forward(delta, tables[i], 0);
+        so_sub_poly_coeffmod(input + i * n, delta, n, m, input + i * n);
+        mul_poly_op(input + i * n, n, r->inv_q_last_mod_q[i], m, input + i * n);
+    }
+    free(neg);
+    free(delta);
+}
+
+uint64_t so_rnstool_inv_q_last_mod_t(const so_rnstool *r)
+{
+    return r->inv_q_last_mod_t;
 }
 
 /* util/rns.cpp:830-901 (CKKS / NTT domain), SEAL_USER_MOD_BIT_COUNT_MAX <= 60 branch (defines.h:47) */
@@ -1208,7 +1245,8 @@ const so_ntt_tables *so_context_tables(const so_context *c, size_t i)
 const so_rnstool *so_context_rnstool(so_context *c, size_t L)
 {
     if (!c->tools[L])
-        c->tools[L] = rnstool_create_ex(c->n, c->primes, L, c->scheme == SO_SCHEME_BFV ? c->plain_modulus : 0,
+        c->tools[L] = rnstool_create_ex(c->n, c->primes, L,
+                                        c->scheme == SO_SCHEME_BFV || c->scheme == SO_SCHEME_BGV ? c->plain_modulus : 0,
                                         c->scheme == SO_SCHEME_BFV);
     return c->tools[L];
 }
@@ -1382,7 +1420,8 @@ void so_switch_key_inplace(const so_context *c, size_t L, uint64_t *encrypted, c
                            const uint64_t *key)
 {
     const size_t n = c->n, k = c->k, d = L, rns = d + 1;
-    const int ckks = c->scheme == SO_SCHEME_CKKS;
+    const int bgv = c->scheme == SO_SCHEME_BGV;
+    const int ckks = c->scheme == SO_SCHEME_CKKS || bgv; /* NTT-form target: :2608, :2639 */
     so_context *cm = (so_context *)c;
     const so_rnstool *key_tool = so_context_rnstool(cm, k);
 
@@ -1454,10 +1493,39 @@ void so_switch_key_inplace(const so_context *c, size_t L, uint64_t *encrypted, c
         }
     }
 
-    /* :2712-2818 non-BGV branch */
     const so_modulus *pk = &c->mod[k - 1];
     const uint64_t qk = pk->value, qk_half = qk >> 1;
-    for (size_t comp = 0; comp < 2; comp++)
+    /* :2715-2758 BGV branch */
+    for (size_t comp = 0; bgv && comp < 2; comp++)
+    {
+        so_modulus tm;
+        so_modulus_init(&tm, c->plain_modulus);
+        uint64_t *t_last = t_poly_prod + (comp * rns + d) * n;
+        uint64_t *kk = (uint64_t *)malloc(sizeof(uint64_t) * n), *cq = (uint64_t *)malloc(sizeof(uint64_t) * n);
+        so_ntt_inverse(t_last, c->tables[k - 1], 0);
+        so_modulo_poly_coeffs(t_last, n, &tm, kk);
+        so_negate_poly_coeffmod(kk, n, &tm, kk);
+        if (key_tool->inv_q_last_mod_t != 1)
+            so_multiply_poly_scalar_coeffmod(kk, n, key_tool->inv_q_last_mod_t, &tm, kk);
+        for (size_t j = 0; j < d; j++)
+        {
+            const so_modulus *m = &c->mod[j];
+            so_modulo_poly_coeffs(kk, n, m, t_ntt);
+            so_multiply_poly_scalar_coeffmod(t_ntt, n, qk, m, t_ntt);
+            so_modulo_poly_coeffs(t_last, n, m, cq);
+            so_add_poly_coeffmod(t_ntt, cq, n, m, t_ntt);
+            so_ntt_forward(t_ntt, c->tables[j], 0);
+            uint64_t *tp = t_poly_prod + (comp * rns + j) * n;
+            so_sub_poly_coeffmod(tp, t_ntt, n, m, tp);
+            mul_poly_op(tp, n, key_tool->inv_q_last_mod_q[j], m, tp);
+            uint64_t *e = encrypted + (comp * d + j) * n;
+            so_add_poly_coeffmod(tp, e, n, m, e);
+        }
+        free(kk);
+        free(cq);
+    }
+    /* :2759-2818 non-BGV branch */
+    for (size_t comp = 0; !bgv && comp < 2; comp++)
     {
         uint64_t *t_last = t_poly_prod + (comp * rns + d) * n;
         so_ntt_inverse(t_last, c->tables[k - 1], 1);
@@ -1513,6 +1581,8 @@ void so_mod_switch_scale_to_next(so_context *c, size_t L, const uint64_t *in, si
     {
         if (c->scheme == SO_SCHEME_CKKS)
             so_divide_and_round_q_last_ntt_inplace(r, copy + p * L * n, c->tables);
+        else if (c->scheme == SO_SCHEME_BGV)
+            so_mod_t_and_divide_q_last_ntt_inplace(r, copy + p * L * n, c->tables);
         else
             so_divide_and_round_q_last_inplace(r, copy + p * L * n);
         memcpy(out + p * (L - 1) * n, copy + p * L * n, sizeof(uint64_t) * (L - 1) * n);
@@ -1537,7 +1607,7 @@ void so_apply_galois_inplace(const so_context *c, size_t L, uint64_t *ct, uint32
     {
         for (size_t i = 0; i < L; i++)
         {
-            if (c->scheme == SO_SCHEME_CKKS)
+            if (c->scheme == SO_SCHEME_CKKS || c->scheme == SO_SCHEME_BGV) /* :2430-2443 */
                 so_apply_galois_ntt(ct + (p * L + i) * n, c->log_n, elt, temp + i * n);
             else
                 so_apply_galois(ct + (p * L + i) * n, c->log_n, elt, &c->mod[i], temp + i * n);
@@ -1658,6 +1728,8 @@ static void encrypt_zero_ntt(const so_context *c, const size_t *limbs, size_t nl
         for (size_t l = 0; l < n; l++)
             c1[i * n + l] = rng_next(r) % m->value;
         so_ntt_forward(c0 + i * n, c->tables[limbs[i]], 0);
+        if (c->scheme == SO_SCHEME_BGV) /* noise = t e (rlwe.cpp:379-385) */
+            so_multiply_poly_scalar_coeffmod(c0 + i * n, n, c->plain_modulus, m, c0 + i * n);
         for (size_t l = 0; l < n; l++)
         {
             uint64_t as = so_multiply_uint_mod(c1[i * n + l], sk[limbs[i] * n + l], m);

@@ -105,6 +105,8 @@ size_t so_rnstool_base_Bsk_size(const so_rnstool *r);
 void so_rnstool_base_Bsk(const so_rnstool *r, uint64_t *out); /* B primes then m_sk */
 uint64_t so_rnstool_m_tilde(const so_rnstool *r);
 void so_rnstool_inv_q_last_mod_q(const so_rnstool *r, uint64_t *operands);
+uint64_t so_rnstool_inv_q_last_mod_t(const so_rnstool *r);
+void so_mod_t_and_divide_q_last_ntt_inplace(const so_rnstool *r, uint64_t *input, so_ntt_tables *const *tables);
 void so_divide_and_round_q_last_inplace(const so_rnstool *r, uint64_t *input);
 void so_divide_and_round_q_last_ntt_inplace(const so_rnstool *r, uint64_t *input, so_ntt_tables *const *tables);
 void so_fastbconv_m_tilde(const so_rnstool *r, const uint64_t *in, uint64_t *out);
@@ -116,7 +118,7 @@ void so_fast_convert_array(const uint64_t *ibase, size_t isz, const uint64_t *ob
                            const uint64_t *in, size_t count, uint64_t *out);
 
 /* ---- Evaluator-level context + ops (context.cu:607-765, evaluator.cpp) ---- */
-enum { SO_SCHEME_BFV = 1, SO_SCHEME_CKKS = 2 };
+enum { SO_SCHEME_BFV = 1, SO_SCHEME_CKKS = 2, SO_SCHEME_BGV = 3 }; /* encryptionparams.h scheme_type */
 
 typedef struct so_context so_context;
 /* primes: the key-level modulus chain (k primes, the last is the special prime). */

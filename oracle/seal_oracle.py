@@ -16,6 +16,7 @@ _SO = os.path.join(_HERE, "libseal_oracle.so")
 
 SCHEME_BFV = 1
 SCHEME_CKKS = 2
+SCHEME_BGV = 3
 
 u64 = C.c_uint64
 u64p = C.POINTER(C.c_uint64)
@@ -95,6 +96,8 @@ def lib() -> C.CDLL:
             "so_rnstool_base_Bsk": (None, [vp, u64p]),
             "so_rnstool_m_tilde": (u64, [vp]),
             "so_rnstool_inv_q_last_mod_q": (None, [vp, u64p]),
+            "so_rnstool_inv_q_last_mod_t": (u64, [vp]),
+            "so_mod_t_and_divide_q_last_ntt_inplace": (None, [vp, u64p, C.POINTER(vp)]),
             "so_divide_and_round_q_last_inplace": (None, [vp, u64p]),
             "so_divide_and_round_q_last_ntt_inplace": (None, [vp, u64p, C.POINTER(vp)]),
             "so_fastbconv_m_tilde": (None, [vp, u64p, u64p]),
@@ -242,6 +245,16 @@ class RNSTool:
         x = arr(x).copy()
         tp = (C.c_void_p * len(tables))(*[t.h for t in tables])
         lib().so_divide_and_round_q_last_ntt_inplace(self.h, ptr(x), tp)
+        return x
+
+    @property
+    def inv_q_last_mod_t(self) -> int:
+        return int(lib().so_rnstool_inv_q_last_mod_t(self.h))
+
+    def mod_t_and_divide_q_last_ntt_inplace(self, x, tables: list[NTTTables]):
+        x = arr(x).copy()
+        tp = (C.c_void_p * len(tables))(*[t.h for t in tables])
+        lib().so_mod_t_and_divide_q_last_ntt_inplace(self.h, ptr(x), tp)
         return x
 
     def _run(self, fn, x, out_limbs):

@@ -147,6 +147,45 @@ def test_bfv_multiply_relin_decrypts(oracle):
     assert decode(rot) == [v % t for v in automorphism(m1, elt)]
 
 
+def test_bgv_multiply_relin_modswitch_rotate_decrypts(oracle):
+    """BGV (evaluator.cpp:710-786 multiply, :2715-2758 key-switch branch, util/rns.cpp:1203-1246 mod switch): the
+    reference holds no known answers for these; decrypt-and-compare as its Evaluator tests do.  A BGV ciphertext
+    decrypts as [c0 + c1 s]_q = m * correction + t e, message = that mod t times correction^-1."""
+    t = 65537
+    primes = oracle.coeff_modulus_create(N, [50, 40, 40, 50])
+    ctx = oracle.Context(LOG_N, primes, oracle.SCHEME_BGV, t)
+    sk = ctx.secret_key(13)
+    L = 3
+    q = primes[:L]
+    rng = np.random.default_rng(8)
+    m1 = [int(v) for v in rng.integers(0, t, N)]
+    m2 = [int(v) for v in rng.integers(0, t, N)]
+    c1 = ctx.encrypt(L, sk, to_rns(m1, q), 53, True)
+    c2 = ctx.encrypt(L, sk, to_rns(m2, q), 54, True)
+
+    def decode(ct, qs, correction=1):
+        ph, _ = crt_centered(ctx.decrypt_phase(sk, ct, True), qs)
+        inv = pow(correction, -1, t)
+        return [(p % t) * inv % t for p in ph]
+
+    assert decode(c1, q) == m1
+    exp = [v % t for v in negacyclic_mul(m1, m2)]
+    c3 = ctx.ckks_multiply(c1, c2)  # bgv_multiply is the same tensor product on NTT-form data
+    assert decode(c3, q) == exp
+    c2r = ctx.relinearize(c3, ctx.relin_key(sk, 62))
+    assert decode(c2r, q) == exp
+    # mod switch: correction factor picks up q_last^-1 mod t (evaluator.cpp:1274-1279)
+    cs = ctx.rescale(c2r)
+    corr = pow(q[-1], -1, t)
+    assert decode(cs, q[:2], corr) == exp
+    elt = 3
+    rot = ctx.apply_galois_inplace(c1, elt, ctx.galois_key(sk, elt, 72))
+    assert decode(rot, q) == [v % t for v in automorphism(m1, elt)]
+    # RNSTool level: the constant the correction factor uses
+    tool = oracle.RNSTool(N, q, t)
+    assert tool.inv_q_last_mod_t == corr
+
+
 def test_ntt_convolution_theorem(oracle):
     # the negacyclic NTT diagonalises multiplication mod x^N+1 (pins output semantics of a1/a2/a4)
     q = oracle.get_primes(2 * N, 60, 1)[0]
