@@ -43,6 +43,8 @@ SIGNATURES = {
     "cat_sub_scalar": (C.c_int, [vp, vp, u64p, vp, u32p, C.c_uint32, C.c_uint32, vp]),
     "cat_modulo": (C.c_int, [vp, vp, vp, u32p, C.c_uint32, C.c_uint32, vp]),
     "cat_ckks_multiply": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
+    "cat_bgv_multiply": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
+    "cat_bgv_inv_q_last_mod_t": (C.c_uint64, [vp, C.c_uint32]),
     "cat_ckks_square": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_multiply_plain_ntt": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "cat_add_plain": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),

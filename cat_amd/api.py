@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 
-SCHEME_NONE, SCHEME_BFV, SCHEME_CKKS = 0, 1, 2
+SCHEME_NONE, SCHEME_BFV, SCHEME_CKKS, SCHEME_BGV = 0, 1, 2, 3
 
 _EXC = {1: ValueError, 2: RuntimeError, 3: IndexError, 4: RuntimeError, 5: MemoryError}
 
@@ -159,6 +159,16 @@ class Context:
         out = torch.empty((b, 3, L, self.n), dtype=torch.int64, device=x.device) if out is None else out
         _check(self.lib.cat_ckks_multiply(self.h, self._p(x), self._p(y), self._p(out), L, b, self._stream()))
         return out
+
+    def bgv_multiply(self, x, y, out=None):
+        """x, y: [batch, 2, L, N] NTT form -> [batch, 3, L, N] (evaluator.cpp:710-841)"""
+        b, _, L, _ = x.shape
+        out = torch.empty((b, 3, L, self.n), dtype=torch.int64, device=x.device) if out is None else out
+        _check(self.lib.cat_bgv_multiply(self.h, self._p(x), self._p(y), self._p(out), L, b, self._stream()))
+        return out
+
+    def bgv_inv_q_last_mod_t(self, L: int) -> int:
+        return int(self.lib.cat_bgv_inv_q_last_mod_t(self.h, L))
 
     def ckks_square(self, x, out=None):
         """x: [batch, 2, L, N] -> [batch, 3, L, N]"""

@@ -123,7 +123,7 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
         return fail(CAT_ERR_INVALID_ARG, "poly_modulus_degree is invalid");
     if (!primes || n_primes == 0 || n_primes > CAT_MAX_MODULI)
         return fail(CAT_ERR_INVALID_ARG, "coeff_modulus is invalid");
-    if (scheme != CAT_SCHEME_NONE && scheme != CAT_SCHEME_BFV && scheme != CAT_SCHEME_CKKS)
+    if (scheme != CAT_SCHEME_NONE && scheme != CAT_SCHEME_BFV && scheme != CAT_SCHEME_CKKS && scheme != CAT_SCHEME_BGV)
         return fail(CAT_ERR_INVALID_ARG, "unsupported scheme");
     const size_t n = size_t(1) << log_n;
     for (uint32_t i = 0; i < n_primes; ++i)
@@ -137,7 +137,7 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
             if (primes[j] == q)
                 return fail(CAT_ERR_INVALID_ARG, "coeff_modulus is invalid");
     }
-    if (scheme == CAT_SCHEME_BFV && (plain_modulus < 2 || (plain_modulus >> 60) != 0))
+    if ((scheme == CAT_SCHEME_BFV || scheme == CAT_SCHEME_BGV) && (plain_modulus < 2 || (plain_modulus >> 60) != 0))
         return fail(CAT_ERR_INVALID_ARG, "plain_modulus is invalid");
     CAT_HIP(hipSetDevice(device));
 
@@ -214,6 +214,7 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
         const uint32_t k = ctx->k;
         ctx->h_inv_mod.assign((size_t)k * k, MulOp{ 0, 0 });
         ctx->h_half_mod.assign((size_t)k * k, 0);
+        std::vector<MulOp> q_mod((size_t)k * k, MulOp{ 0, 0 });
         for (uint32_t a = 0; a < k; ++a)
             for (uint32_t b = 0; b < k; ++b)
             {
@@ -225,7 +226,17 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
                     throw std::logic_error("invalid rns bases");
                 ctx->h_inv_mod[(size_t)a * k + b] = MulOp{ iv, mb.shoup(iv) };
                 ctx->h_half_mod[(size_t)a * k + b] = (ctx->hmods[a].q >> 1) % mb.q;
+                q_mod[(size_t)a * k + b] = MulOp{ ctx->hmods[a].q % mb.q, mb.shoup(ctx->hmods[a].q % mb.q) };
             }
+        if (scheme == CAT_SCHEME_BGV)
+        {
+            // RNSTool::initialize, util/rns.cpp:767-776: inv_q_last_mod_t of every level (and of the key level)
+            ctx->pt = HostMod(plain_modulus);
+            ctx->inv_q_mod_t.assign(k, 0);
+            for (uint32_t a = 0; a < k; ++a)
+                if (!invert_mod(ctx->hmods[a].q % plain_modulus, plain_modulus, ctx->inv_q_mod_t[a]))
+                    throw std::logic_error("invalid rns bases");
+        }
         cat_status st = upload_vec(&ctx->d_mods, dm);
         if (st == CAT_OK)
             st = upload_vec(&ctx->d_tw_fwd, fwd);
@@ -241,6 +252,8 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
             st = upload_vec(&ctx->d_inv_mod, ctx->h_inv_mod);
         if (st == CAT_OK)
             st = upload_vec(&ctx->d_half_mod, ctx->h_half_mod);
+        if (st == CAT_OK)
+            st = upload_vec(&ctx->d_q_mod, q_mod);
         if (st == CAT_OK && scheme == CAT_SCHEME_BFV)
             st = build_bfv_levels(ctx);
         if (st != CAT_OK)
@@ -283,6 +296,7 @@ cat_status cat_ctx_destroy(cat_ctx *ctx)
     if (ctx->d_nttmods) (void)hipFree(ctx->d_nttmods);
     if (ctx->d_inv_mod) (void)hipFree(ctx->d_inv_mod);
     if (ctx->d_half_mod) (void)hipFree(ctx->d_half_mod);
+    if (ctx->d_q_mod) (void)hipFree(ctx->d_q_mod);
     if (ctx->ws) (void)hipFree(ctx->ws);
     delete ctx;
     return CAT_OK;
@@ -511,6 +525,20 @@ cat_status cat_ckks_multiply(cat_ctx *ctx, const uint64_t *x, const uint64_t *y,
     if (out == x || out == y)
         return fail(CAT_ERR_INVALID_ARG, "destination must not alias the inputs");
     return launch_ckks_tensor(ctx, (const u64 *)x, (const u64 *)y, (u64 *)out, L, batch, (hipStream_t)s);
+}
+
+cat_status cat_bgv_multiply(cat_ctx *ctx, const uint64_t *x, const uint64_t *y, uint64_t *out, uint32_t L,
+                            uint32_t batch, cat_stream s)
+{
+    // Evaluator::bgv_multiply (evaluator.cpp:710-841) computes the same three dyadic combinations
+    return cat_ckks_multiply(ctx, x, y, out, L, batch, s);
+}
+
+uint64_t cat_bgv_inv_q_last_mod_t(const cat_ctx *ctx, uint32_t L)
+{
+    if (!ctx || ctx->scheme != CAT_SCHEME_BGV || L == 0 || L > ctx->k)
+        return 0;
+    return ctx->inv_q_mod_t[L - 1];
 }
 
 cat_status cat_ckks_square(cat_ctx *ctx, const uint64_t *x, uint64_t *out, uint32_t L, uint32_t batch, cat_stream s)
@@ -751,7 +779,7 @@ cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, co
         return CAT_ERR_NOMEM;
     u64 *perm = ws + ks_words;
     const u64 *tgt = perm + (size_t)L * N;
-    const bool ntt = ctx->scheme == CAT_SCHEME_CKKS;
+    const bool ntt = ctx->scheme == CAT_SCHEME_CKKS || ctx->scheme == CAT_SCHEME_BGV; // :2429
     st = launch_galois(ctx, ntt, (const u64 *)ct, perm, elt, ctx->identity_map(), L, batch * 2, (hipStream_t)s);
     if (st != CAT_OK)
         return st;

@@ -61,6 +61,10 @@ struct cat_ctx
     std::vector<MulOp> h_inv_mod;
     cat::u64 *d_half_mod = nullptr; // [k][k]: entry [a][b] = (q_a >> 1) mod q_b
     std::vector<cat::u64> h_half_mod;
+    MulOp *d_q_mod = nullptr; // [k][k]: entry [a][b] = q_a mod q_b as a multiply operand modulo q_b (BGV)
+    // BGV (util/rns.cpp:767-776): the plain modulus t and q_i^-1 mod t for every coefficient prime
+    cat::HostMod pt;
+    std::vector<cat::u64> inv_q_mod_t;
 
     void *ws = nullptr;
     size_t ws_bytes = 0;

@@ -10,6 +10,9 @@
 //  step 3  inner product with the key in 128-bit accumulators, one Barrett-128       :2658-2708
 //  step 4  mod-down: INTT_P(t_last), +P/2, Barrett-64; per limb: reduce, +fix,
 //          NTT (CKKS) / INTT of the product (BFV), subtract, * P^-1, add to ct       :2759-2818
+//          BGV: the correction is t_last + P * [-t_last P^-1]_t instead of rounding  :2715-2758
+// BGV shares steps 1-3 with CKKS (NTT-form ciphertexts) and, for mod switching,
+// RNSTool::mod_t_and_divide_q_last_ntt_inplace (util/rns.cpp:1203-1246).
 #include "context.hpp"
 #include "rows8.cuh"
 #include <cstdlib>
@@ -279,6 +282,7 @@ namespace
         const DevMod *mods;
         const MulOp *inv_mod; // [k][k]
         const u64 *half_mod;  // [k][k]
+        const MulOp *q_mod;   // [k][k]: q_a mod q_b as a multiply operand
         u32 d, k, log_n;
         int lazy_shift;  // qi_lazy = q << lazy_shift (2 for CKKS, 1 for BFV)
         u64 enc_stride2; // vectors between consecutive ciphertexts in enc
@@ -311,6 +315,45 @@ namespace
             const u64 fix = m.q - g.half_mod[(g.k - 1) * g.k + j];
             v.x += fix;
             v.y += fix;
+            reinterpret_cast<ulonglong2 *>(g.tmp)[i] = v;
+        }
+    }
+
+    // BGV: the plain modulus t with Q^-1 mod t (Q = the prime being divided out), by value
+    struct BgvArgs
+    {
+        u64 t, t_ratio1;
+        MulOp inv_Q; // Q^-1 mod t as a multiply operand modulo t
+    };
+
+    // v canonical modulo Q.  k = [-v Q^-1]_t (evaluator.cpp:2727-2732, rns.cpp:1215-1222);
+    // delta = ((k mod q) (Q mod q) + (v mod q)) mod q (evaluator.cpp:2738-2748, rns.cpp:1228-1237): v + k Q is
+    // divisible by Q and congruent to 0 modulo t, so subtracting it keeps the plaintext.
+    __device__ __forceinline__ u64 bgv_delta(u64 v, const BgvArgs &pt, const DevMod &m, const MulOp &Qm)
+    {
+        u64 k = neg_mod(barrett64(v, pt.t, pt.t_ratio1), pt.t);
+        k = mul_shoup(k, pt.inv_Q.op, pt.inv_Q.quo, pt.t);
+        const u64 d = mul_shoup(barrett64(k, m.q, m.ratio1), Qm.op, Qm.quo, m.q);
+        return add_mod(d, barrett64(v, m.q, m.ratio1), m.q);
+    }
+
+    // BGV: tmp[b][comp][j] = delta_j(t_last), t_last = INTT_P (canonical) of the special-prime product
+    __global__ __launch_bounds__(256) void ks_down_prepare_bgv_kernel(DownArgs g, BgvArgs pt)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1);
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 r = i >> (g.log_n - 1);
+            const u32 j = (u32)(r % g.d);
+            const u64 bc = r / g.d; // b*2 + comp
+            const DevMod m = g.mods[j];
+            const MulOp Qm = g.q_mod[(g.k - 1) * g.k + j];
+            ulonglong2 v =
+                reinterpret_cast<const ulonglong2 *>(g.prod)[((bc * (g.d + 1) + g.d) << (g.log_n - 1)) + c];
+            v.x = bgv_delta(v.x, pt, m, Qm);
+            v.y = bgv_delta(v.y, pt, m, Qm);
             reinterpret_cast<ulonglong2 *>(g.tmp)[i] = v;
         }
     }
@@ -351,6 +394,7 @@ namespace
         const DevMod *mods;
         const MulOp *inv_mod;
         const u64 *half_mod;
+        const MulOp *q_mod;
         u32 L, k, log_n, size;
         u64 last_stride2; // vectors between consecutive `last` polys
         u64 in_stride2;   // vectors between consecutive input ciphertexts
@@ -393,6 +437,26 @@ namespace
             const u64 neg_half = m.q - g.half_mod[(g.L - 1) * g.k + li];
             v.x += neg_half;
             v.y += neg_half;
+            reinterpret_cast<ulonglong2 *>(g.tmp)[i] = v;
+        }
+    }
+
+    // BGV: tmp[p][i] = delta_i(last), last = INTT (canonical) of the last limb            rns.cpp:1211-1237
+    __global__ __launch_bounds__(256) void rescale_prepare_bgv_kernel(RescaleArgs g, BgvArgs pt)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1);
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 r = i >> (g.log_n - 1);
+            const u32 li = (u32)(r % (g.L - 1));
+            const u64 p = r / (g.L - 1);
+            const DevMod m = g.mods[li];
+            const MulOp Qm = g.q_mod[(g.L - 1) * g.k + li];
+            ulonglong2 v = reinterpret_cast<const ulonglong2 *>(g.last)[p * g.last_stride2 + c];
+            v.x = bgv_delta(v.x, pt, m, Qm);
+            v.y = bgv_delta(v.y, pt, m, Qm);
             reinterpret_cast<ulonglong2 *>(g.tmp)[i] = v;
         }
     }
@@ -459,6 +523,15 @@ namespace
         }
     }
 
+    BgvArgs bgv_args(const cat_ctx *ctx, u32 q_index)
+    {
+        BgvArgs a;
+        a.t = ctx->pt.q;
+        a.t_ratio1 = ctx->pt.ratio1;
+        a.inv_Q = MulOp{ ctx->inv_q_mod_t[q_index], ctx->pt.shoup(ctx->inv_q_mod_t[q_index]) };
+        return a;
+    }
+
     u32 grid_for(u64 items)
     {
         u64 blocks = (items + 255) / 256;
@@ -477,7 +550,8 @@ namespace cat
     {
         const u32 d = L, k = ctx->k, rns = d + 1, log_n = ctx->log_n;
         const size_t N = ctx->n;
-        const bool ckks = ctx->scheme == CAT_SCHEME_CKKS;
+        const bool bgv = ctx->scheme == CAT_SCHEME_BGV;
+        const bool ckks = ctx->scheme == CAT_SCHEME_CKKS || bgv; // NTT-form ciphertexts (:2608, :2635)
         const size_t w_target = (size_t)batch * d * N;
         const size_t w_ext = (size_t)batch * rns * d * N;
         const size_t w_prod = (size_t)batch * 2 * rns * N;
@@ -581,7 +655,8 @@ namespace cat
         {
             LimbMap mp{};
             mp.id[0] = (unsigned char)(k - 1);
-            cat_status st = launch_ntt_ex(ctx, false, prod + (size_t)d * N, mp, 1, batch * 2, true, (u64)rns * N, 1,
+            // the BGV branch transforms back fully (:2724), the others lazily (:2763)
+            cat_status st = launch_ntt_ex(ctx, false, prod + (size_t)d * N, mp, 1, batch * 2, !bgv, (u64)rns * N, 1,
                                           false, s);
             if (st != CAT_OK)
                 return st;
@@ -592,12 +667,41 @@ namespace cat
             g.mods = ctx->d_mods;
             g.inv_mod = ctx->d_inv_mod;
             g.half_mod = ctx->d_half_mod;
+            g.q_mod = ctx->d_q_mod;
             g.d = d;
             g.k = k;
             g.log_n = log_n;
             g.lazy_shift = ckks ? 2 : 1;
             g.enc_stride2 = enc_stride / 2;
             g.total2 = w_tmp / 2;
+            if (bgv)
+            {
+                // delta (canonical) by its own kernel, then its forward transform; the subtraction, the product with
+                // P^-1 and the accumulation (:2749-2756) are the same finish step as CKKS, on a lazy transform
+                hipLaunchKernelGGL(ks_down_prepare_bgv_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g,
+                                   bgv_args(ctx, k - 1));
+                CAT_HIP(hipGetLastError());
+                if (log_n >= 12)
+                {
+                    NttFuse f;
+                    f.ep_other = prod;
+                    f.ep_other_b = (u64)2 * rns * N;
+                    f.ep_other_s = (u64)rns * N;
+                    f.ep_dest = enc;
+                    f.ep_dest_b = enc_stride;
+                    f.ep_dest_s = (u64)d * N;
+                    f.ep_S = 2;
+                    f.ep_acc = 1;
+                    f.ep_qidx = k - 1;
+                    return launch_ntt_ex(ctx, true, tmp, ident, d, batch * 2, true, (u64)d * N, 1, false, s, false, &f);
+                }
+                st = launch_ntt(ctx, true, tmp, ident, d, batch * 2, true, s);
+                if (st != CAT_OK)
+                    return st;
+                hipLaunchKernelGGL(ks_down_finish_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+                CAT_HIP(hipGetLastError());
+                return CAT_OK;
+            }
             if (ckks && log_n >= 12)
             {
                 // prepare and finish fused into the two passes of the forward transform of tmp (NttFuse)
@@ -642,6 +746,7 @@ namespace cat
         const u64 *out_end = out + (size_t)(batch ? batch - 1 : 0) * out_stride + (size_t)size * (L - 1) * N;
         const bool alias = !(out_end <= in || in_end <= out);
         const bool ckks = ctx->scheme != CAT_SCHEME_BFV;
+        const bool bgv = ctx->scheme == CAT_SCHEME_BGV;
         u64 *ws = (u64 *)workspace(ctx, (w_last + 2 * w_tmp) * sizeof(u64));
         if (!ws)
             return CAT_ERR_NOMEM;
@@ -654,6 +759,7 @@ namespace cat
         g.mods = ctx->d_mods;
         g.inv_mod = ctx->d_inv_mod;
         g.half_mod = ctx->d_half_mod;
+        g.q_mod = ctx->d_q_mod;
         g.L = L;
         g.k = ctx->k;
         g.log_n = ctx->log_n;
@@ -674,13 +780,22 @@ namespace cat
             cat_status st = launch_ntt(ctx, false, last, ml, 1, (uint32_t)polys, false, s);
             if (st != CAT_OK)
                 return st;
+            if (bgv)
+            {
+                hipLaunchKernelGGL(rescale_prepare_bgv_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g,
+                                   bgv_args(ctx, L - 1));
+                CAT_HIP(hipGetLastError());
+            }
             if (ctx->log_n >= 12)
             {
                 NttFuse f;
-                f.src = last;
-                f.src_stride = N;
-                f.src_kind = 1;
-                f.src_qidx = L - 1;
+                if (!bgv)
+                {
+                    f.src = last;
+                    f.src_stride = N;
+                    f.src_kind = 1;
+                    f.src_qidx = L - 1;
+                }
                 f.ep_other = in;
                 f.ep_other_b = in_stride;
                 f.ep_other_s = (u64)L * N;
@@ -700,8 +815,11 @@ namespace cat
                                              (size_t)size * (L - 1) * N * sizeof(u64), batch, hipMemcpyDeviceToDevice, s));
                 return CAT_OK;
             }
-            hipLaunchKernelGGL(rescale_prepare_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
-            CAT_HIP(hipGetLastError());
+            if (!bgv)
+            {
+                hipLaunchKernelGGL(rescale_prepare_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+                CAT_HIP(hipGetLastError());
+            }
             st = launch_ntt(ctx, true, tmp, ctx->identity_map(), L - 1, (uint32_t)polys, true, s);
             if (st != CAT_OK)
                 return st;

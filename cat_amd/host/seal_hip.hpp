@@ -35,7 +35,8 @@ namespace seal
     {
         none = 0x0,
         bfv = 0x1,
-        ckks = 0x2
+        ckks = 0x2,
+        bgv = 0x3
     };
 
     namespace detail
@@ -173,6 +174,7 @@ namespace seal
             n_ = o.n_;
             is_ntt_form_ = o.is_ntt_form_;
             scale_ = o.scale_;
+            correction_factor_ = o.correction_factor_;
             reserve_words(o.words());
             size_ = o.size_;
             L_ = o.L_;
@@ -202,6 +204,7 @@ namespace seal
                 n_ = o.n_;
                 is_ntt_form_ = o.is_ntt_form_;
                 scale_ = o.scale_;
+                correction_factor_ = o.correction_factor_;
                 o.d_ = nullptr;
                 o.cap_ = o.size_ = o.L_ = 0;
             }
@@ -310,6 +313,15 @@ namespace seal
         {
             return scale_;
         }
+        // BGV only (ciphertext.h correction_factor): decryption divides the message by it modulo t
+        std::uint64_t correction_factor() const noexcept
+        {
+            return correction_factor_;
+        }
+        std::uint64_t &correction_factor() noexcept
+        {
+            return correction_factor_;
+        }
         std::size_t words() const noexcept
         {
             return size_ * L_ * n_;
@@ -347,6 +359,7 @@ namespace seal
         std::size_t cap_ = 0, size_ = 0, L_ = 0, n_ = 0;
         bool is_ntt_form_ = false;
         double scale_ = 1.0;
+        std::uint64_t correction_factor_ = 1;
     };
 
     // Device-resident NTT-form CKKS plaintext: coeff_modulus_size x N words (plaintext.h; produced by CKKSEncoder on
@@ -624,6 +637,14 @@ namespace seal
                 detail::check(cat_bfv_multiply(h(), encrypted1.d_data(), encrypted2.d_data(), dest.d_data(), L, 1, nullptr));
                 dest.scale() = encrypted1.scale();
                 break;
+            case scheme_type::bgv: // evaluator.cpp:710-841
+                if (!encrypted1.is_ntt_form() || !encrypted2.is_ntt_form())
+                    throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
+                detail::check(cat_bgv_multiply(h(), encrypted1.d_data(), encrypted2.d_data(), dest.d_data(), L, 1, nullptr));
+                dest.is_ntt_form() = true;
+                dest.scale() = encrypted1.scale();
+                dest.correction_factor() = mul_mod_t(encrypted1.correction_factor(), encrypted2.correction_factor());
+                break;
             default:
                 throw std::invalid_argument("unsupported scheme");
             }
@@ -726,7 +747,7 @@ namespace seal
             encrypted = std::move(dest);
         }
 
-        // evaluator.cpp:1347-1389: BFV -> mod_switch_scale_to_next, CKKS -> mod_switch_drop_to_next
+        // evaluator.cpp:1384-1419: BFV and BGV -> mod_switch_scale_to_next, CKKS -> mod_switch_drop_to_next
         void mod_switch_to_next_inplace(Ciphertext &encrypted) const
         {
             verify(encrypted, "encrypted");
@@ -737,6 +758,13 @@ namespace seal
             {
                 if (encrypted.is_ntt_form())
                     throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+                scale_to_next(encrypted, dest);
+                dest.scale() = encrypted.scale();
+            }
+            else if (context_.parms().scheme() == scheme_type::bgv)
+            {
+                if (!encrypted.is_ntt_form())
+                    throw std::invalid_argument("BGV encrypted must be in NTT form");
                 scale_to_next(encrypted, dest);
                 dest.scale() = encrypted.scale();
             }
@@ -800,8 +828,8 @@ namespace seal
         }
         void rotate_rows_inplace(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys) const
         {
-            if (context_.parms().scheme() != scheme_type::bfv)
-                throw std::logic_error("unsupported scheme");
+            if (context_.parms().scheme() != scheme_type::bfv && context_.parms().scheme() != scheme_type::bgv)
+                throw std::logic_error("unsupported scheme"); // evaluator.h:1063
             rotate_internal(encrypted, steps, galois_keys);
         }
         void complex_conjugate_inplace(Ciphertext &encrypted, const GaloisKeys &galois_keys) const
@@ -837,6 +865,14 @@ namespace seal
                 throw std::invalid_argument("NTT form mismatch");
             if (a.scale() != b.scale())
                 throw std::invalid_argument("scale mismatch");
+            // evaluator.cpp:168-199 balances BGV operands whose correction factors differ; host bookkeeping plus two
+            // scalar multiplications that this facade does not restate
+            if (a.correction_factor() != b.correction_factor())
+                throw std::logic_error("unsupported: operands with different correction factors");
+        }
+        std::uint64_t mul_mod_t(std::uint64_t a, std::uint64_t b) const
+        {
+            return (std::uint64_t)((unsigned __int128)a * b % context_.parms().plain_modulus());
         }
         void plain_addsub(Ciphertext &encrypted, const Plaintext &plain, bool sub) const
         {
@@ -862,6 +898,8 @@ namespace seal
             dest.is_ntt_form() = encrypted.is_ntt_form();
             if (context_.parms().scheme() == scheme_type::ckks)
                 dest.scale() = encrypted.scale() / (double)cat_ctx_modulus(h(), L - 1);
+            else if (context_.parms().scheme() == scheme_type::bgv) // :1274-1279
+                dest.correction_factor() = mul_mod_t(encrypted.correction_factor(), cat_bgv_inv_q_last_mod_t(h(), L));
             destination = std::move(dest);
         }
         void rotate_internal(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys) const

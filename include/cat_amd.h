@@ -44,7 +44,7 @@ typedef enum {
     CAT_ERR_NOMEM = 5
 } cat_status;
 
-enum { CAT_SCHEME_NONE = 0, CAT_SCHEME_BFV = 1, CAT_SCHEME_CKKS = 2 };
+enum { CAT_SCHEME_NONE = 0, CAT_SCHEME_BFV = 1, CAT_SCHEME_CKKS = 2, CAT_SCHEME_BGV = 3 }; /* scheme_type, encryptionparams.h */
 
 #define CAT_MAX_MODULI 64 /* coefficient primes + BFV auxiliary primes per context */
 #define CAT_MAX_LOG_N 16
@@ -60,7 +60,8 @@ const char *cat_last_error(void);
  * ratios (modulus.cpp:87-98), q_a^-1 mod q_b tables (util/rns.cpp:767-776) and, for BFV, the BEHZ
  * bases of every level (util/rns.cpp:578-787), and uploads them to `device`.
  * primes[0..n_primes) is the key-level chain; when n_primes > 1 the last prime is the special prime
- * of key switching.  plain_modulus is used by BFV only. */
+ * of key switching.  plain_modulus is used by BFV and BGV (BGV: it must be coprime to every prime, since the
+ * levels hold q_last^-1 mod t, util/rns.cpp:767-776). */
 cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_primes, int scheme,
                           uint64_t plain_modulus, int device, cat_ctx **out);
 cat_status cat_ctx_destroy(cat_ctx *ctx);
@@ -122,6 +123,18 @@ cat_status cat_modulo(cat_ctx *ctx, const uint64_t *d_a, uint64_t *d_out, const 
  * not alias the inputs. */
 cat_status cat_ckks_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, uint64_t *d_out, uint32_t L,
                              uint32_t batch, cat_stream s);
+
+/* ---- f4 ("next" row 4): BGV ----------------------------------------------------------------
+ * With a CAT_SCHEME_BGV context (NTT-form ciphertexts) cat_switch_key / cat_relinearize /
+ * cat_apply_galois_inplace take the BGV mod-down branch (evaluator.cpp:2715-2758) and cat_rescale[_strided] is
+ * RNSTool::mod_t_and_divide_q_last_ntt_inplace (util/rns.cpp:1203-1246) = mod_switch_to_next.
+ * Evaluator::bgv_multiply, size 2 x 2 -> 3 (evaluator.cpp:710-841): same layout and contract as cat_ckks_multiply. */
+cat_status cat_bgv_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, uint64_t *d_out, uint32_t L,
+                            uint32_t batch, cat_stream s);
+/* RNSTool::inv_q_last_mod_t() of the level with L limbs (util/rns.cpp:778-786): the factor mod switching multiplies
+ * into Ciphertext::correction_factor() (evaluator.cpp:1274-1279; bookkeeping stays with the caller).  0 when the
+ * context is not BGV or L is out of range. */
+uint64_t cat_bgv_inv_q_last_mod_t(const cat_ctx *ctx, uint32_t L);
 
 /* ---- f1 ("next" row 1): squares and plaintext operands, same layout and kernels' arithmetic -------
  * Evaluator::ckks_square, size 2 -> 3 (evaluator.cpp:1022-1078): (c0^2, 2 c0 c1, c1^2); d_out must not alias d_x. */

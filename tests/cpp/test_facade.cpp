@@ -269,6 +269,72 @@ static void test_bfv()
     so_context_destroy(oc);
 }
 
+// BGV through the facade: multiply, relinearize, mod_switch_to_next with the correction-factor
+// bookkeeping of evaluator.cpp:838-840 and :1274-1279, rotate_rows
+static void test_bgv()
+{
+    const int log_n = 12;
+    const size_t n = 4096;
+    const int bits[4] = { 50, 40, 40, 50 };
+    const uint64_t t = 65537;
+    vec primes(4);
+    EXPECT(so_coeff_modulus_create(n, bits, 4, primes.data()) == 0);
+    const size_t k = 4, L = 3;
+    so_context *oc = so_context_create(log_n, primes.data(), k, SO_SCHEME_BGV, t);
+
+    EncryptionParameters parms(scheme_type::bgv);
+    parms.set_poly_modulus_degree(n);
+    parms.set_coeff_modulus(primes);
+    parms.set_plain_modulus(t);
+    SEALContext context(parms);
+    Evaluator evaluator(context);
+
+    vec sk(k * n), rk((k - 1) * 2 * k * n), gk(rk.size());
+    so_sample_ternary_ntt(oc, 1, sk.data());
+    so_gen_relin_key(oc, sk.data(), 2, rk.data());
+    const uint32_t elt = so_galois_elt_from_step(log_n, 1);
+    so_gen_galois_key(oc, sk.data(), elt, 3, gk.data());
+    RelinKeys relin_keys(context);
+    relin_keys.set_key(0, rk.data());
+    GaloisKeys galois_keys(context);
+    galois_keys.set_key(GaloisKeys::get_index(elt), gk.data());
+
+    vec x = uniform(oc, L, 2, n, 30), y = uniform(oc, L, 2, n, 31);
+    Ciphertext encrypted1(context, L), encrypted2(context, L);
+    encrypted1.upload(x.data());
+    encrypted2.upload(y.data());
+    EXPECT(throws<std::invalid_argument>([&] { evaluator.multiply_inplace(encrypted1, encrypted2); })); // :712
+    encrypted1.is_ntt_form() = encrypted2.is_ntt_form() = true;
+    encrypted1.correction_factor() = 3;
+    encrypted2.correction_factor() = 5;
+
+    vec exp3(3 * L * n, 0);
+    std::memcpy(exp3.data(), x.data(), x.size() * 8);
+    so_ckks_multiply(oc, L, exp3.data(), y.data()); // the same tensor product (evaluator.cpp:770-798)
+    evaluator.multiply_inplace(encrypted1, encrypted2);
+    EXPECT(encrypted1.size() == 3 && encrypted1.to_cpu() == exp3 && encrypted1.correction_factor() == 15);
+    so_relinearize(oc, L, exp3.data(), rk.data());
+    evaluator.relinearize_inplace(encrypted1, relin_keys);
+    vec exp2(exp3.begin(), exp3.begin() + 2 * L * n);
+    EXPECT(encrypted1.to_cpu() == exp2);
+
+    vec e(2 * (L - 1) * n);
+    so_mod_switch_scale_to_next(oc, L, exp2.data(), 2, e.data());
+    evaluator.mod_switch_to_next_inplace(encrypted1);
+    uint64_t inv = 0;
+    EXPECT(so_try_invert_uint_mod(primes[L - 1] % t, t, &inv) == 1);
+    EXPECT(encrypted1.coeff_modulus_size() == L - 1 && encrypted1.is_ntt_form() && encrypted1.to_cpu() == e);
+    EXPECT(encrypted1.correction_factor() == 15 * inv % t);
+    EXPECT(throws<std::invalid_argument>([&] { evaluator.rescale_to_next_inplace(encrypted2); }));
+
+    vec r = y;
+    so_apply_galois_inplace(oc, L, r.data(), elt, gk.data());
+    evaluator.rotate_rows_inplace(encrypted2, 1, galois_keys);
+    EXPECT(encrypted2.to_cpu() == r);
+    EXPECT(throws<std::logic_error>([&] { evaluator.rotate_vector_inplace(encrypted2, 1, galois_keys); }));
+    so_context_destroy(oc);
+}
+
 int main()
 {
     try
@@ -276,6 +342,7 @@ int main()
         test_util_ntt_known_answers();
         test_ckks();
         test_bfv();
+        test_bgv();
     }
     catch (const std::exception &e)
     {

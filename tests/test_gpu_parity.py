@@ -382,6 +382,61 @@ def test_bfv_switch_key_rescale_and_galois_branches(cat, oracle):
     ctx.close()
 
 
+BGV_CASES = [
+    # (log_n, bit sizes of the key-level chain, plain modulus)
+    (12, [50, 40, 40, 50], 65537),
+    (13, [60, 60, 60, 60, 60], 786433),   # all-60-bit chain: the special prime is the largest
+    (10, [30, 27, 30], 12289),            # N < 4096: unfused prepare / finish kernels
+    (12, [36, 36, 37], (1 << 40) + 15),   # t larger than the primes: k mod q_i reduces (rns.cpp:1228)
+]
+
+
+@pytest.mark.parametrize("log_n,bits,t", BGV_CASES)
+def test_bgv_multiply_relinearize_modswitch_rotate(cat, oracle, log_n, bits, t):
+    """the BGV branch of key switching (evaluator.cpp:2715-2758), mod_switch_to_next =
+    RNSTool::mod_t_and_divide_q_last_ntt_inplace (util/rns.cpp:1203-1246), bgv_multiply (:710-841) and the
+    NTT-form Galois path, every level, bit-exact against the oracle."""
+    n = 1 << log_n
+    primes = oracle.coeff_modulus_create(n, bits)
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_BGV, t)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_BGV, t)
+    k = len(primes)
+    sk = octx.secret_key(21)
+    rk = octx.relin_key(sk, 22)
+    drk = dev(rk)
+    batch = 3
+    for L in range(k - 1, 0, -1):
+        x = np.stack([octx.uniform(L, 2, 3000 + 10 * L + b) for b in range(batch)])
+        y = np.stack([octx.uniform(L, 2, 4000 + 10 * L + b) for b in range(batch)])
+        prod = ctx.bgv_multiply(dev(x), dev(y))
+        exp3 = np.stack([octx.ckks_multiply(x[b], y[b]) for b in range(batch)])
+        assert (host(prod) == exp3).all(), f"bgv_multiply L={L}"
+        relin = ctx.relinearize(prod, drk).contiguous()
+        exp2 = np.stack([octx.relinearize(exp3[b], rk) for b in range(batch)])
+        assert (host(relin) == exp2).all(), f"bgv relinearize L={L}"
+        tgt = np.stack([octx.uniform(L, 1, 5000 + b + L)[0] for b in range(batch)])
+        got = host(ctx.switch_key(dev(x), dev(tgt), drk))
+        assert (got == np.stack([octx.switch_key_inplace(x[b], tgt[b], rk) for b in range(batch)])).all()
+        elt = cat.galois_elt_from_step(log_n, 1)
+        gk = octx.galois_key(sk, elt, 23)
+        got = host(ctx.apply_galois_inplace(dev(x), elt, dev(gk)))
+        assert (got == np.stack([octx.apply_galois_inplace(x[b], elt, gk) for b in range(batch)])).all(), f"rotate L={L}"
+        if L >= 2:
+            res = ctx.rescale(relin)
+            expr = np.stack([octx.rescale(exp2[b]) for b in range(batch)])
+            assert (host(res) == expr).all(), f"bgv mod switch L={L}"
+            buf = dev(exp2)
+            ctx.rescale(buf, out=buf.view(-1)[: batch * 2 * (L - 1) * n].view(batch, 2, L - 1, n))
+            assert (host(buf).reshape(-1)[: expr.size] == expr.reshape(-1)).all()
+            # the correction-factor constant (evaluator.cpp:1274-1279)
+            assert ctx.bgv_inv_q_last_mod_t(L) == pow(primes[L - 1], -1, t)
+    ctx.close()
+    if primes[0] < (1 << 58):
+        # a prime that is not invertible modulo t: logic_error("invalid rns bases"), util/rns.cpp:780-783
+        with pytest.raises(RuntimeError):
+            cat.Context(log_n, primes, cat.SCHEME_BGV, 2 * primes[0])
+
+
 def test_rescale_reference_known_answers(cat, oracle):
     # tests/util/rns.cpp:1013-1072 through the HIP path: q = {53, 13}, N = 2
     g = KA["divide_and_round_q_last_ntt"]

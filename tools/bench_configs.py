@@ -117,12 +117,41 @@ def config5(steps):
             "ops_per_s": B / dt, "ms_per_slice": dt * 1e3, "s_per_1024_pairs": 1024 / (B / dt), "parity_checked": ok}
 
 
+def config6(steps):
+    """Not a BASELINE config: the BGV row at config 5's parameters, multiply + relinearize +
+    mod_switch_to_next."""
+    log_n, n, t = 15, 32768, 786433
+    primes = so.bfv_default(n)
+    octx = so.Context(log_n, primes, so.SCHEME_BGV, t)
+    ctx = cat_amd.Context(log_n, primes, cat_amd.SCHEME_BGV, t)
+    L, B = 15, 64
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(6)
+    x, y = uniform(primes[:L], (B, 2), n, gen), uniform(primes[:L], (B, 2), n, gen)
+    rk = octx.relin_key(octx.secret_key(1), 2)
+    drk = to_device(rk)
+    out = torch.empty((B, 3, L, n), dtype=torch.int64, device="cuda")
+    res = torch.empty((B, 2, L - 1, n), dtype=torch.int64, device="cuda")
+
+    def step():
+        ctx.bgv_multiply(x, y, out=out)
+        ctx.relinearize(out, drk)
+        ctx.rescale_strided(out, 2, res)
+
+    step()
+    exp = octx.rescale(octx.relinearize(octx.ckks_multiply(to_host(x[0]), to_host(y[0])), rk))
+    ok = bool((to_host(res[0]) == exp).all())
+    dt = timed(step, steps)
+    return {"config": 6, "workload": f"BGV N=32768, 16-prime BFVDefault (15 + special), t=786433, multiply + relinearize + mod_switch_to_next, batch {B}",
+            "ops_per_s": B / dt, "ms_per_step": dt * 1e3, "parity_checked": ok}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--only", type=int, default=0, help="run one configuration (3, 4 or 5)")
+    ap.add_argument("--only", type=int, default=0, help="run one configuration (3, 4, 5, or 6 = the BGV row)")
     a = ap.parse_args()
-    for f in (config3, config4, config5):
+    for f in (config3, config4, config5, config6):
         if a.only and f.__name__ != f"config{a.only}":
             continue
         print(json.dumps(f(a.steps)), flush=True)
