@@ -7,7 +7,7 @@ HDR := include/cat_amd.h cat_amd/csrc/context.hpp cat_amd/csrc/host_math.hpp cat
 OBJ := $(patsubst cat_amd/csrc/%,build/%.o,$(SRC))
 LIB := cat_amd/lib/libcat_amd.so
 
-all: $(LIB) oracle facade_test
+all: $(LIB) oracle facade_test random_test
 
 $(LIB): $(OBJ)
 	@mkdir -p cat_amd/lib
@@ -26,12 +26,17 @@ oracle:
 
 # C++ facade parity test (needs a GPU to run; plain g++: the facade only sees the C ABI)
 facade_test: tests/cpp/facade_test
-tests/cpp/facade_test: tests/cpp/test_facade.cpp cat_amd/host/seal_hip.hpp include/cat_amd.h $(LIB) oracle
+tests/cpp/facade_test: tests/cpp/test_facade.cpp cat_amd/host/seal_hip.hpp cat_amd/host/seal_hip_random.hpp cat_amd/host/seal_hip_crypto.hpp include/cat_amd.h $(LIB) oracle
 	g++ -std=c++17 -O2 -Wall $< -o $@ -Lcat_amd/lib -lcat_amd -Loracle -lseal_oracle \
 	    -Wl,-rpath,'$$ORIGIN/../../cat_amd/lib' -Wl,-rpath,'$$ORIGIN/../../oracle' -Wl,-rpath-link,/opt/rocm/lib
+
+# host-only check of the facade's PRNG and samplers against the oracle (and oracle/_ref at run time)
+random_test: tests/cpp/random_test
+tests/cpp/random_test: tests/cpp/test_random.cpp cat_amd/host/seal_hip_random.hpp oracle
+	g++ -std=c++17 -O2 -Wall $< -o $@ -Loracle -lseal_oracle -ldl -Wl,-rpath,'$$ORIGIN/../../oracle'
 
 clean:
 	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean facade_test
+.PHONY: all oracle clean facade_test random_test

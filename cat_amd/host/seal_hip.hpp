@@ -29,6 +29,8 @@
 #include <utility>
 #include <vector>
 
+#include "seal_hip_random.hpp"
+
 namespace seal
 {
     enum class scheme_type : std::uint8_t
@@ -95,12 +97,22 @@ namespace seal
         {
             return t_;
         }
+        // encryptionparams.cuh set_random_generator / random_generator: nullptr = the default factory
+        void set_random_generator(std::shared_ptr<UniformRandomGeneratorFactory> random_generator) noexcept
+        {
+            random_generator_ = std::move(random_generator);
+        }
+        std::shared_ptr<UniformRandomGeneratorFactory> random_generator() const
+        {
+            return random_generator_ ? random_generator_ : UniformRandomGeneratorFactory::DefaultFactory();
+        }
 
     private:
         scheme_type scheme_;
         std::size_t n_ = 0;
         std::vector<std::uint64_t> q_;
         std::uint64_t t_ = 0;
+        std::shared_ptr<UniformRandomGeneratorFactory> random_generator_;
     };
 
     // SEALContext for this path: the modulus chain, per-prime NTT tables and per-level RNS tools live in the
@@ -382,6 +394,17 @@ namespace seal
         {
             return buf_.d_data();
         }
+        std::uint64_t *d_data() noexcept
+        {
+            return buf_.d_data();
+        }
+        // the coeff_modulus_size x N words of the plaintext
+        std::vector<std::uint64_t> to_cpu() const
+        {
+            std::vector<std::uint64_t> all = buf_.to_cpu();
+            all.resize(all.size() / 2);
+            return all;
+        }
         std::size_t coeff_modulus_size() const noexcept
         {
             return buf_.coeff_modulus_size();
@@ -438,6 +461,24 @@ namespace seal
                 detail::check(cat_malloc(ctx_->handle(), key_words() * 8, (void **)&keys_[index]));
             detail::check(cat_upload(ctx_->handle(), keys_[index], host, key_words() * 8, nullptr));
             detail::check(cat_stream_sync(ctx_->handle(), nullptr));
+        }
+        // device storage of one entry, for keys generated on the device (KeyGenerator, seal_hip_crypto.hpp)
+        std::uint64_t *allocate_key(std::size_t index)
+        {
+            if (!ctx_->using_keyswitching())
+                throw std::logic_error("keyswitching is not supported by the context");
+            if (keys_.size() <= index)
+                keys_.resize(index + 1, nullptr);
+            if (!keys_[index])
+                detail::check(cat_malloc(ctx_->handle(), key_words() * 8, (void **)&keys_[index]));
+            return keys_[index];
+        }
+        std::vector<std::uint64_t> key_to_cpu(std::size_t index) const
+        {
+            std::vector<std::uint64_t> out(key_words());
+            detail::check(cat_download(ctx_->handle(), out.data(), d_key(index), out.size() * 8, nullptr));
+            detail::check(cat_stream_sync(ctx_->handle(), nullptr));
+            return out;
         }
         bool has_index(std::size_t index) const noexcept
         {

@@ -1,0 +1,522 @@
+// seal_hip_crypto.hpp -- key generation, encryption and decryption of the facade with the
+// reference's class names: SecretKey, PublicKey, KeyGenerator (keygenerator.cpp:56-363), Encryptor
+// (encryptor.cpp:84-324), Decryptor (decryptor.cu:544-670) and util::encrypt_zero_symmetric / _asymmetric
+// (util/rlwe.cpp:189-412).
+//
+// Randomness is drawn on the host exactly as the reference draws it (seal_hip_random.hpp: Blake2xb PRNG, ternary /
+// centred-binomial / uniform samplers), so a fixed-seed factory gives the reference's keys and ciphertexts; every
+// polynomial operation (NTT, dyadic products, sums, Galois permutation of the secret key, the modulus switch of a
+// public-key encryption) runs on the device through the C ABI.  A level is named by its limb count L as in
+// seal_hip.hpp; the key level has all k primes.
+//
+// Not restated: seeded (save_seed) ciphertexts, which belong to serialization (row f3); plaintext encoding and the
+// BFV/BGV plaintext lift (`encrypt(plain)` is the CKKS branch; BFV/BGV callers use encrypt_zero and the phase);
+// the RNS tail of BFV/BGV decryption (RNSTool::decrypt_scale_and_round / decrypt_modt, out of scope in SURVEY
+// section 2) -- Decryptor exposes the phase c0 + c1 s + ... of any scheme and finishes CKKS, whose plaintext IS
+// the phase.
+#pragma once
+
+#include "seal_hip.hpp"
+
+namespace seal
+{
+    namespace detail
+    {
+        // words of device memory owned through the C ABI
+        class DeviceWords
+        {
+        public:
+            DeviceWords(cat_ctx *h, std::size_t words) : h_(h), words_(words)
+            {
+                check(cat_malloc(h_, words * 8, (void **)&d_));
+            }
+            DeviceWords(cat_ctx *h, const std::vector<std::uint64_t> &host) : DeviceWords(h, host.size())
+            {
+                upload(host.data());
+            }
+            DeviceWords(const DeviceWords &) = delete;
+            DeviceWords &operator=(const DeviceWords &) = delete;
+            ~DeviceWords()
+            {
+                if (d_)
+                    cat_free(h_, d_);
+            }
+            void upload(const std::uint64_t *host)
+            {
+                check(cat_upload(h_, d_, host, words_ * 8, nullptr));
+                check(cat_stream_sync(h_, nullptr));
+            }
+            std::vector<std::uint64_t> to_cpu() const
+            {
+                std::vector<std::uint64_t> out(words_);
+                check(cat_download(h_, out.data(), d_, words_ * 8, nullptr));
+                check(cat_stream_sync(h_, nullptr));
+                return out;
+            }
+            std::uint64_t *get() const noexcept
+            {
+                return d_;
+            }
+            std::size_t words() const noexcept
+            {
+                return words_;
+            }
+
+        private:
+            cat_ctx *h_;
+            std::uint64_t *d_ = nullptr;
+            std::size_t words_;
+        };
+
+        inline std::vector<std::uint64_t> level_primes(const SEALContext &context, std::size_t L)
+        {
+            const auto &q = context.parms().coeff_modulus();
+            if (L == 0 || L > q.size())
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            return std::vector<std::uint64_t>(q.begin(), q.begin() + (std::ptrdiff_t)L);
+        }
+    } // namespace detail
+
+    // secretkey.cuh: the ternary secret in NTT form over all k key-level primes, [k][N] words, device-resident
+    class SecretKey
+    {
+    public:
+        SecretKey() = default;
+        SecretKey(const SEALContext &context, const std::uint64_t *host_ntt_form)
+            : data_(std::make_shared<detail::DeviceWords>(context.handle(), context.key_modulus_size() * context.poly_modulus_degree()))
+        {
+            data_->upload(host_ntt_form);
+        }
+        const std::uint64_t *d_data() const
+        {
+            if (!data_)
+                throw std::logic_error("secret key is not set");
+            return data_->get();
+        }
+        std::vector<std::uint64_t> to_cpu() const
+        {
+            if (!data_)
+                throw std::logic_error("secret key is not set");
+            return data_->to_cpu();
+        }
+        bool is_set() const noexcept
+        {
+            return (bool)data_;
+        }
+
+    private:
+        friend class KeyGenerator;
+        std::shared_ptr<detail::DeviceWords> data_;
+    };
+
+    // publickey.h: an encryption of zero at the key level (2 x k x N words, NTT form)
+    class PublicKey
+    {
+    public:
+        Ciphertext &data() noexcept
+        {
+            return ct_;
+        }
+        const Ciphertext &data() const noexcept
+        {
+            return ct_;
+        }
+
+    private:
+        Ciphertext ct_;
+    };
+
+    namespace util
+    {
+        // util/rlwe.cpp:282-412 without the seed-saving branch: (c0, c1) = (-(a s + e), a), BGV: -(a s + t e).
+        // d_c0, d_c1: L x N device words each.  `a` comes from a second generator seeded with 64 bytes of the
+        // first one (:327-334); the noise from the first one (:360).
+        inline void encrypt_zero_symmetric(const SecretKey &secret_key, const SEALContext &context, std::size_t L,
+                                           bool is_ntt_form, std::uint64_t *d_c0, std::uint64_t *d_c1)
+        {
+            cat_ctx *h = context.handle();
+            const std::size_t n = context.poly_modulus_degree();
+            const std::vector<std::uint64_t> q = detail::level_primes(context, L);
+            const std::uint32_t limbs = (std::uint32_t)L;
+
+            auto bootstrap_prng = context.parms().random_generator()->create();
+            prng_seed_type public_prng_seed;
+            bootstrap_prng->generate(prng_seed_byte_count, public_prng_seed.data());
+            auto ciphertext_prng = UniformRandomGeneratorFactory::DefaultFactory()->create(public_prng_seed);
+
+            std::vector<std::uint64_t> a(L * n), noise(L * n);
+            sample_poly_uniform(ciphertext_prng, q, n, a.data()); // taken as the NTT form of a (:342-346)
+            sample_poly_cbd(bootstrap_prng, q, n, noise.data());
+            detail::check(cat_upload(h, d_c1, a.data(), a.size() * 8, nullptr));
+            detail::check(cat_stream_sync(h, nullptr));
+            detail::DeviceWords d_noise(h, noise);
+
+            detail::check(cat_dyadic(h, secret_key.d_data(), d_c1, d_c0, nullptr, limbs, 1, nullptr)); // :366-368
+            if (is_ntt_form)
+                detail::check(cat_ntt_forward(h, d_noise.get(), nullptr, limbs, 1, 0, nullptr)); // :372
+            else
+                detail::check(cat_ntt_inverse(h, d_c0, nullptr, limbs, 1, 0, nullptr)); // :376
+            if (context.parms().scheme() == scheme_type::bgv)
+            {
+                const std::vector<std::uint64_t> t(L, context.parms().plain_modulus());
+                detail::check(cat_mul_scalar(h, d_noise.get(), t.data(), d_noise.get(), nullptr, limbs, 1, nullptr)); // :379-385
+            }
+            detail::check(cat_add(h, d_noise.get(), d_c0, d_c0, nullptr, limbs, 1, nullptr)); // :388-390
+            detail::check(cat_negate(h, d_c0, d_c0, nullptr, limbs, 1, nullptr));             // :392
+            if (!is_ntt_form)
+                detail::check(cat_ntt_inverse(h, d_c1, nullptr, limbs, 1, 0, nullptr)); // :395-402
+            detail::check(cat_stream_sync(h, nullptr));
+        }
+
+        inline void encrypt_zero_symmetric(const SecretKey &secret_key, const SEALContext &context, std::size_t L,
+                                           bool is_ntt_form, bool save_seed, Ciphertext &destination)
+        {
+            if (save_seed)
+                throw std::logic_error("unsupported: seeded ciphertexts are not restated (serialization)");
+            destination.resize(context, L, 2);
+            destination.is_ntt_form() = is_ntt_form;
+            destination.scale() = 1.0;
+            destination.correction_factor() = 1;
+            encrypt_zero_symmetric(secret_key, context, L, is_ntt_form, destination.d_data(0), destination.d_data(1));
+        }
+
+        // util/rlwe.cpp:189-280: c[j] = pk[j] u + e[j] (BGV: + t e[j]), u ternary; one generator for u, e[0], e[1]
+        inline void encrypt_zero_asymmetric(const PublicKey &public_key, const SEALContext &context, std::size_t L,
+                                            bool is_ntt_form, Ciphertext &destination)
+        {
+            cat_ctx *h = context.handle();
+            const std::size_t n = context.poly_modulus_degree();
+            const std::vector<std::uint64_t> q = detail::level_primes(context, L);
+            const std::uint32_t limbs = (std::uint32_t)L;
+            const Ciphertext &pk = public_key.data();
+            if (pk.size() != 2 || pk.coeff_modulus_size() != context.key_modulus_size() || !pk.is_ntt_form())
+                throw std::invalid_argument("public key is not valid for the encryption parameters");
+            const bool bgv = context.parms().scheme() == scheme_type::bgv;
+
+            destination.resize(context, L, 2);
+            destination.is_ntt_form() = is_ntt_form;
+            destination.scale() = 1.0;
+            destination.correction_factor() = 1;
+
+            auto prng = context.parms().random_generator()->create();
+            std::vector<std::uint64_t> tmp(L * n);
+            sample_poly_ternary(prng, q, n, tmp.data());
+            detail::DeviceWords d_u(h, tmp);
+            detail::check(cat_ntt_forward(h, d_u.get(), nullptr, limbs, 1, 0, nullptr));
+            for (std::size_t j = 0; j < 2; ++j)
+            {
+                // limb i of polynomial j of the key-level public key (its first L limbs are this level's primes)
+                const std::uint64_t *pk_j = pk.d_data() + j * pk.coeff_modulus_size() * n;
+                detail::check(cat_dyadic(h, d_u.get(), pk_j, destination.d_data(j), nullptr, limbs, 1, nullptr));
+                if (!is_ntt_form)
+                    detail::check(cat_ntt_inverse(h, destination.d_data(j), nullptr, limbs, 1, 0, nullptr));
+            }
+            detail::DeviceWords d_e(h, L * n);
+            const std::vector<std::uint64_t> t(L, context.parms().plain_modulus());
+            for (std::size_t j = 0; j < 2; ++j)
+            {
+                sample_poly_cbd(prng, q, n, tmp.data());
+                d_e.upload(tmp.data());
+                if (is_ntt_form) // BGV transforms lazily and reduces in the scalar product (:259-264): same residues
+                    detail::check(cat_ntt_forward(h, d_e.get(), nullptr, limbs, 1, 0, nullptr));
+                if (bgv)
+                    detail::check(cat_mul_scalar(h, d_e.get(), t.data(), d_e.get(), nullptr, limbs, 1, nullptr));
+                detail::check(cat_add(h, d_e.get(), destination.d_data(j), destination.d_data(j), nullptr, limbs, 1, nullptr));
+            }
+            detail::check(cat_stream_sync(h, nullptr));
+        }
+    } // namespace util
+
+    class KeyGenerator
+    {
+    public:
+        // keygenerator.cpp:19-54
+        explicit KeyGenerator(const SEALContext &context) : context_(context)
+        {
+            generate_sk();
+        }
+        KeyGenerator(const SEALContext &context, const SecretKey &secret_key) : context_(context), secret_key_(secret_key)
+        {
+            if (!secret_key.is_set())
+                throw std::invalid_argument("secret key is not valid for encryption parameters");
+        }
+        const SecretKey &secret_key() const
+        {
+            return secret_key_;
+        }
+
+        // generate_pk, keygenerator.cpp:93-120
+        void create_public_key(PublicKey &destination) const
+        {
+            util::encrypt_zero_symmetric(secret_key_, context_, context_.key_modulus_size(), true, false, destination.data());
+        }
+
+        // create_relin_keys, keygenerator.cpp:122-160, count = 1: the new key is s^2 (compute_secret_key_array :232-299)
+        void create_relin_keys(RelinKeys &destination) const
+        {
+            cat_ctx *h = context_.handle();
+            const std::size_t k = context_.key_modulus_size(), n = context_.poly_modulus_degree();
+            detail::DeviceWords s2(h, k * n);
+            detail::check(cat_dyadic(h, secret_key_.d_data(), secret_key_.d_data(), s2.get(), nullptr, (std::uint32_t)k, 1, nullptr));
+            generate_one_kswitch_key(s2.get(), destination.allocate_key(RelinKeys::get_index(2)));
+        }
+
+        // create_galois_keys, keygenerator.cpp:162-221
+        void create_galois_keys(const std::vector<std::uint32_t> &galois_elts, GaloisKeys &destination) const
+        {
+            cat_ctx *h = context_.handle();
+            const std::size_t k = context_.key_modulus_size(), n = context_.poly_modulus_degree();
+            detail::DeviceWords rotated(h, k * n);
+            for (std::uint32_t galois_elt : galois_elts)
+            {
+                if (!(galois_elt & 1) || galois_elt >= (n << 1))
+                    throw std::invalid_argument("Galois element is not valid");
+                if (destination.has_key(galois_elt))
+                    continue;
+                detail::check(cat_apply_galois_ntt(h, secret_key_.d_data(), rotated.get(), galois_elt, (std::uint32_t)k, 1, nullptr));
+                generate_one_kswitch_key(rotated.get(), destination.allocate_key(GaloisKeys::get_index(galois_elt)));
+            }
+        }
+        // by rotation steps (keygenerator.h create_galois_keys(const vector<int> &steps, ...))
+        void create_galois_keys(const std::vector<int> &steps, GaloisKeys &destination) const
+        {
+            std::vector<std::uint32_t> elts;
+            for (int s : steps)
+            {
+                const std::uint32_t e = cat_galois_elt_from_step(cat_ctx_log_n(context_.handle()), s);
+                if (!e)
+                    throw std::invalid_argument("step count too large");
+                elts.push_back(e);
+            }
+            create_galois_keys(elts, destination);
+        }
+
+    private:
+        // keygenerator.cpp:56-91
+        void generate_sk()
+        {
+            const std::size_t k = context_.key_modulus_size(), n = context_.poly_modulus_degree();
+            std::vector<std::uint64_t> s(k * n);
+            util::sample_poly_ternary(context_.parms().random_generator()->create(), context_.parms().coeff_modulus(), n, s.data());
+            secret_key_.data_ = std::make_shared<detail::DeviceWords>(context_.handle(), s);
+            detail::check(cat_ntt_forward(context_.handle(), secret_key_.data_->get(), nullptr, (std::uint32_t)k, 1, 0, nullptr));
+            detail::check(cat_stream_sync(context_.handle(), nullptr));
+        }
+
+        // keygenerator.cpp:301-334: entry J is an encryption of zero at the key level whose c0 gets
+        // (P mod q_J) * new_key added in limb J.  d_dest: [k-1][2][k][N]
+        void generate_one_kswitch_key(const std::uint64_t *d_new_key, std::uint64_t *d_dest) const
+        {
+            if (!context_.using_keyswitching())
+                throw std::logic_error("keyswitching is not supported by the context");
+            cat_ctx *h = context_.handle();
+            const std::size_t k = context_.key_modulus_size(), n = context_.poly_modulus_degree();
+            const std::size_t decomp_mod_count = context_.first_level_size();
+            const auto &key_modulus = context_.parms().coeff_modulus();
+            detail::DeviceWords temp(h, n);
+            for (std::size_t J = 0; J < decomp_mod_count; ++J)
+            {
+                std::uint64_t *c0 = d_dest + (J * 2) * k * n, *c1 = c0 + k * n;
+                util::encrypt_zero_symmetric(secret_key_, context_, k, true, c0, c1);
+                const std::uint64_t factor = key_modulus.back() % key_modulus[J];
+                const std::uint32_t id = (std::uint32_t)J;
+                detail::check(cat_mul_scalar(h, d_new_key + J * n, &factor, temp.get(), &id, 1, 1, nullptr));
+                detail::check(cat_add(h, c0 + J * n, temp.get(), c0 + J * n, &id, 1, 1, nullptr));
+            }
+            detail::check(cat_stream_sync(h, nullptr));
+        }
+
+        SEALContext context_;
+        SecretKey secret_key_;
+    };
+
+    class Encryptor
+    {
+    public:
+        Encryptor(const SEALContext &context, const PublicKey &public_key) : context_(context)
+        {
+            set_public_key(public_key);
+        }
+        Encryptor(const SEALContext &context, const SecretKey &secret_key) : context_(context), secret_key_(secret_key)
+        {}
+        Encryptor(const SEALContext &context, const PublicKey &public_key, const SecretKey &secret_key)
+            : context_(context), secret_key_(secret_key)
+        {
+            set_public_key(public_key);
+        }
+        void set_public_key(const PublicKey &public_key)
+        {
+            public_key_.data() = public_key.data();
+            has_public_key_ = true;
+        }
+        void set_secret_key(const SecretKey &secret_key)
+        {
+            secret_key_ = secret_key;
+        }
+
+        // encryptor.h encrypt_zero(parms_id, destination): the level is named by its limb count
+        void encrypt_zero(std::size_t coeff_modulus_size, Ciphertext &destination) const
+        {
+            encrypt_zero_internal(coeff_modulus_size, true, destination);
+        }
+        void encrypt_zero(Ciphertext &destination) const
+        {
+            encrypt_zero_internal(context_.first_level_size(), true, destination);
+        }
+        void encrypt_zero_symmetric(std::size_t coeff_modulus_size, Ciphertext &destination) const
+        {
+            encrypt_zero_internal(coeff_modulus_size, false, destination);
+        }
+        void encrypt_zero_symmetric(Ciphertext &destination) const
+        {
+            encrypt_zero_internal(context_.first_level_size(), false, destination);
+        }
+
+        // encrypt_internal, CKKS branch (encryptor.cpp:218-244): the NTT-form plaintext is added to c0
+        void encrypt(const Plaintext &plain, Ciphertext &destination) const
+        {
+            encrypt_plain(plain, true, destination);
+        }
+        void encrypt_symmetric(const Plaintext &plain, Ciphertext &destination) const
+        {
+            encrypt_plain(plain, false, destination);
+        }
+
+    private:
+        // encryptor.cpp:84-180
+        void encrypt_zero_internal(std::size_t L, bool is_asymmetric, Ciphertext &destination) const
+        {
+            if (is_asymmetric && !has_public_key_)
+                throw std::logic_error("public key is not set");
+            if (!is_asymmetric && !secret_key_.is_set())
+                throw std::logic_error("secret key is not set");
+            const scheme_type scheme = context_.parms().scheme();
+            bool is_ntt_form = false;
+            if (scheme == scheme_type::ckks || scheme == scheme_type::bgv)
+                is_ntt_form = true;
+            else if (scheme != scheme_type::bfv)
+                throw std::invalid_argument("unsupported scheme");
+            if (L == 0 || L > context_.key_modulus_size())
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            if (!is_asymmetric)
+            {
+                util::encrypt_zero_symmetric(secret_key_, context_, L, is_ntt_form, false, destination);
+                return;
+            }
+            if (L == context_.key_modulus_size())
+            {
+                util::encrypt_zero_asymmetric(public_key_, context_, L, is_ntt_form, destination);
+                return;
+            }
+            // a level below the key level: encrypt one level up, then switch the modulus down (:124-166)
+            Ciphertext temp;
+            util::encrypt_zero_asymmetric(public_key_, context_, L + 1, is_ntt_form, temp);
+            destination.resize(context_, L, 2);
+            detail::check(cat_rescale(context_.handle(), temp.d_data(), destination.d_data(), (std::uint32_t)(L + 1), 2, 1, nullptr));
+            detail::check(cat_stream_sync(context_.handle(), nullptr));
+            destination.is_ntt_form() = is_ntt_form;
+            destination.scale() = temp.scale();
+            destination.correction_factor() = temp.correction_factor();
+        }
+        void encrypt_plain(const Plaintext &plain, bool is_asymmetric, Ciphertext &destination) const
+        {
+            if (context_.parms().scheme() != scheme_type::ckks)
+                throw std::logic_error("unsupported: the plaintext lift of BFV/BGV is not restated; use encrypt_zero");
+            if (!plain.is_ntt_form())
+                throw std::invalid_argument("plain must be in NTT form");
+            const std::size_t L = plain.coeff_modulus_size();
+            encrypt_zero_internal(L, is_asymmetric, destination);
+            detail::check(cat_add(context_.handle(), destination.d_data(0), plain.d_data(), destination.d_data(0), nullptr,
+                                  (std::uint32_t)L, 1, nullptr));
+            detail::check(cat_stream_sync(context_.handle(), nullptr));
+            destination.scale() = plain.scale();
+        }
+
+        SEALContext context_;
+        PublicKey public_key_;
+        bool has_public_key_ = false;
+        SecretKey secret_key_;
+    };
+
+    class Decryptor
+    {
+    public:
+        Decryptor(const SEALContext &context, const SecretKey &secret_key) : context_(context), secret_key_(secret_key)
+        {
+            if (!secret_key.is_set())
+                throw std::invalid_argument("secret key is not valid for encryption parameters");
+        }
+
+        // dot_product_ct_sk_array (decryptor.cu:544-626): d_destination (L x N device words) = c0 + c1 s + c2 s^2 + ...
+        // in the form (NTT or coefficient) of the ciphertext.  For BFV and BGV this phase is what
+        // RNSTool::decrypt_scale_and_round / decrypt_modt would finish.
+        void dot_product_ct_sk_array(const Ciphertext &encrypted, std::uint64_t *d_destination)
+        {
+            cat_ctx *h = context_.handle();
+            const std::size_t n = context_.poly_modulus_degree(), k = context_.key_modulus_size();
+            const std::size_t L = encrypted.coeff_modulus_size(), size = encrypted.size();
+            if (!encrypted.d_data() || size < 2 || L == 0 || L > k)
+                throw std::invalid_argument("encrypted is not valid for encryption parameters");
+            const std::uint32_t limbs = (std::uint32_t)L;
+            compute_secret_key_array(size - 1);
+            // c_1 ... c_{size-1} in NTT form (the reference transforms lazily, :582 and :603: same residues)
+            detail::DeviceWords copy(h, (size - 1) * L * n);
+            std::vector<std::uint64_t> host = encrypted.to_cpu();
+            copy.upload(host.data() + L * n);
+            if (!encrypted.is_ntt_form())
+                detail::check(cat_ntt_forward(h, copy.get(), nullptr, limbs, (std::uint32_t)(size - 1), 0, nullptr));
+            for (std::size_t p = 0; p + 1 < size; ++p)
+            {
+                std::uint64_t *c = copy.get() + p * L * n;
+                detail::check(cat_dyadic(h, c, powers_->get() + p * k * n, c, nullptr, limbs, 1, nullptr));
+                if (p)
+                    detail::check(cat_add(h, copy.get(), c, copy.get(), nullptr, limbs, 1, nullptr));
+            }
+            if (!encrypted.is_ntt_form())
+                detail::check(cat_ntt_inverse(h, copy.get(), nullptr, limbs, 1, 0, nullptr));
+            detail::check(cat_add(h, copy.get(), encrypted.d_data(), d_destination, nullptr, limbs, 1, nullptr));
+            detail::check(cat_stream_sync(h, nullptr));
+        }
+
+        // decrypt -> ckks_decrypt (decryptor.cu:628-670): the plaintext is the phase, NTT form, at the level and scale
+        // of the ciphertext
+        void decrypt(const Ciphertext &encrypted, Plaintext &destination)
+        {
+            if (context_.parms().scheme() != scheme_type::ckks)
+                throw std::logic_error("unsupported: BFV/BGV decryption ends in the RNS tool's scale-and-round; use "
+                                       "dot_product_ct_sk_array for the phase");
+            if (!encrypted.is_ntt_form())
+                throw std::invalid_argument("encrypted must be in NTT form");
+            if (destination.coeff_modulus_size() != encrypted.coeff_modulus_size())
+                destination = Plaintext(context_, encrypted.coeff_modulus_size());
+            dot_product_ct_sk_array(encrypted, destination.d_data());
+            destination.is_ntt_form() = true;
+            destination.scale() = encrypted.scale();
+        }
+
+    private:
+        // decryptor.cpp:160-223: powers s, s^2, ... of the secret key, [power][k][N], NTT form
+        void compute_secret_key_array(std::size_t max_power)
+        {
+            if (max_power <= powers_count_)
+                return;
+            cat_ctx *h = context_.handle();
+            const std::size_t n = context_.poly_modulus_degree(), k = context_.key_modulus_size();
+            auto next = std::make_shared<detail::DeviceWords>(h, max_power * k * n);
+            std::vector<std::uint64_t> s = secret_key_.to_cpu();
+            detail::check(cat_upload(h, next->get(), s.data(), s.size() * 8, nullptr));
+            detail::check(cat_stream_sync(h, nullptr));
+            for (std::size_t p = 1; p < max_power; ++p)
+                detail::check(cat_dyadic(h, next->get() + (p - 1) * k * n, next->get(), next->get() + p * k * n, nullptr,
+                                         (std::uint32_t)k, 1, nullptr));
+            detail::check(cat_stream_sync(h, nullptr));
+            powers_ = std::move(next);
+            powers_count_ = max_power;
+        }
+
+        SEALContext context_;
+        SecretKey secret_key_;
+        std::shared_ptr<detail::DeviceWords> powers_;
+        std::size_t powers_count_ = 0;
+    };
+} // namespace seal

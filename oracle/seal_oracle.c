@@ -1840,3 +1840,433 @@ void so_decrypt_phase(const so_context *c, size_t L, const uint64_t *sk, const u
     free(t);
     free(sp);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * the reference's own randomness -- Blake2xb PRNG (randomgen.cpp:176-211, randomgen.h:300-560),
+ * RLWE samplers (util/rlwe.cpp:21-131), key generation (keygenerator.cpp:56-363), encrypt_zero_symmetric /
+ * _asymmetric (util/rlwe.cpp:189-412), Encryptor::encrypt_zero_internal (encryptor.cpp:84-180) and
+ * Decryptor::dot_product_ct_sk_array (decryptor.cu:544-626).  A "factory seed" plays the role of a
+ * Blake2xbPRNGFactory(default_seed): every create() starts a generator from that same seed (randomgen.h:436-447).
+ * BLAKE2b follows RFC 7693, BLAKE2Xb the reference's util/blake2xb.c:32-149; tests/test_random_keys.py checks both
+ * against the reference's C files compiled as they lie (oracle/_ref/libblake2_ref.so).
+ * ---------------------------------------------------------------------------------------------- */
+
+static const uint64_t b2_iv[8] = { 0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                   0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL };
+static const uint8_t b2_sigma[10][16] = {
+    { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 }, { 14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3 },
+    { 11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4 }, { 7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8 },
+    { 9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13 }, { 2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9 },
+    { 12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11 }, { 13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10 },
+    { 6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5 }, { 10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0 }
+};
+
+static inline uint64_t b2_rotr(uint64_t x, int c)
+{
+    return (x >> c) | (x << (64 - c));
+}
+
+/* RFC 7693 3.2: compression of one 128-byte block; t = bytes hashed so far including this block */
+static void b2_compress(uint64_t h[8], const uint8_t block[128], uint64_t t, int last)
+{
+    uint64_t m[16], v[16];
+    memcpy(m, block, 128);
+    for (int i = 0; i < 8; i++)
+    {
+        v[i] = h[i];
+        v[i + 8] = b2_iv[i];
+    }
+    v[12] ^= t; /* inputs stay far below 2^64 bytes: the high counter word is zero */
+    if (last)
+        v[14] = ~v[14];
+#define B2_G(a, b, c, d, x, y)            \
+    v[a] = v[a] + v[b] + (x);             \
+    v[d] = b2_rotr(v[d] ^ v[a], 32);      \
+    v[c] = v[c] + v[d];                   \
+    v[b] = b2_rotr(v[b] ^ v[c], 24);      \
+    v[a] = v[a] + v[b] + (y);             \
+    v[d] = b2_rotr(v[d] ^ v[a], 16);      \
+    v[c] = v[c] + v[d];                   \
+    v[b] = b2_rotr(v[b] ^ v[c], 63);
+    for (int r = 0; r < 12; r++)
+    {
+        const uint8_t *s = b2_sigma[r % 10];
+        B2_G(0, 4, 8, 12, m[s[0]], m[s[1]])
+        B2_G(1, 5, 9, 13, m[s[2]], m[s[3]])
+        B2_G(2, 6, 10, 14, m[s[4]], m[s[5]])
+        B2_G(3, 7, 11, 15, m[s[6]], m[s[7]])
+        B2_G(0, 5, 10, 15, m[s[8]], m[s[9]])
+        B2_G(1, 6, 11, 12, m[s[10]], m[s[11]])
+        B2_G(2, 7, 8, 13, m[s[12]], m[s[13]])
+        B2_G(3, 4, 9, 14, m[s[14]], m[s[15]])
+    }
+#undef B2_G
+    for (int i = 0; i < 8; i++)
+        h[i] ^= v[i] ^ v[i + 8];
+}
+
+/* hash of a whole message given as up to two pieces (an optional 128-byte key block, then the input) under a
+ * 64-byte parameter block */
+static void b2_hash(const uint8_t param[64], const uint8_t *key_block, const uint8_t *in, size_t inlen, uint8_t *out,
+                    size_t outlen)
+{
+    uint64_t h[8];
+    for (int i = 0; i < 8; i++)
+    {
+        uint64_t w;
+        memcpy(&w, param + 8 * i, 8);
+        h[i] = b2_iv[i] ^ w;
+    }
+    size_t total = (key_block ? 128 : 0) + inlen;
+    size_t blocks = total ? (total + 127) / 128 : 1;
+    for (size_t b = 0; b < blocks; b++)
+    {
+        uint8_t block[128];
+        memset(block, 0, 128);
+        size_t start = b * 128, end = start + 128 < total ? start + 128 : total;
+        for (size_t pos = start; pos < end; pos++)
+            block[pos - start] = (key_block && pos < 128) ? key_block[pos] : in[pos - (key_block ? 128 : 0)];
+        b2_compress(h, block, end, b + 1 == blocks);
+    }
+    uint8_t full[64];
+    memcpy(full, h, 64);
+    memcpy(out, full, outlen);
+}
+
+int so_blake2b(void *out, size_t outlen, const void *in, size_t inlen, const void *key, size_t keylen)
+{
+    if (!out || !outlen || outlen > 64 || keylen > 64 || (!in && inlen) || (!key && keylen))
+        return -1;
+    uint8_t param[64] = { 0 }, kb[128] = { 0 };
+    param[0] = (uint8_t)outlen;
+    param[1] = (uint8_t)keylen;
+    param[2] = 1;
+    param[3] = 1;
+    if (keylen)
+        memcpy(kb, key, keylen);
+    b2_hash(param, keylen ? kb : NULL, (const uint8_t *)in, inlen, (uint8_t *)out, outlen);
+    return 0;
+}
+
+/* util/blake2xb.c:36-181 */
+int so_blake2xb(void *out, size_t outlen, const void *in, size_t inlen, const void *key, size_t keylen)
+{
+    if (!out || !outlen || outlen > 0xFFFFFFFFUL || keylen > 64 || (!in && inlen) || (!key && keylen))
+        return -1;
+    uint8_t param[64] = { 0 }, kb[128] = { 0 }, root[64];
+    uint32_t xof = (uint32_t)outlen, leaf = 64;
+    param[0] = 64;
+    param[1] = (uint8_t)keylen;
+    param[2] = 1;
+    param[3] = 1;
+    memcpy(param + 12, &xof, 4);
+    if (keylen)
+        memcpy(kb, key, keylen);
+    b2_hash(param, keylen ? kb : NULL, (const uint8_t *)in, inlen, root, 64);
+    param[1] = param[2] = param[3] = 0; /* :119-125 */
+    memcpy(param + 4, &leaf, 4);
+    param[16] = 0;
+    param[17] = 64;
+    for (uint32_t i = 0; outlen > 0; i++)
+    {
+        size_t bs = outlen < 64 ? outlen : 64;
+        param[0] = (uint8_t)bs;
+        memcpy(param + 8, &i, 4);
+        b2_hash(param, NULL, root, 64, (uint8_t *)out + (size_t)i * 64, bs);
+        outlen -= bs;
+    }
+    return 0;
+}
+
+#define SO_PRNG_BUFFER 4096 /* randomgen.h:391 */
+struct so_prng
+{
+    uint64_t seed[8];
+    uint64_t counter;
+    size_t head;
+    uint8_t buffer[SO_PRNG_BUFFER];
+};
+
+so_prng *so_prng_create(const uint64_t seed[8])
+{
+    so_prng *p = (so_prng *)calloc(1, sizeof(*p));
+    memcpy(p->seed, seed, 64);
+    p->head = SO_PRNG_BUFFER; /* empty: the first draw refills (randomgen.h:331-336) */
+    return p;
+}
+
+void so_prng_destroy(so_prng *p)
+{
+    free(p);
+}
+
+/* randomgen.cpp:176-211 */
+void so_prng_generate(so_prng *p, size_t count, void *dest)
+{
+    uint8_t *d = (uint8_t *)dest;
+    while (count)
+    {
+        size_t cur = SO_PRNG_BUFFER - p->head;
+        if (cur > count)
+            cur = count;
+        memcpy(d, p->buffer + p->head, cur);
+        p->head += cur;
+        d += cur;
+        count -= cur;
+        if (p->head == SO_PRNG_BUFFER)
+        {
+            so_blake2xb(p->buffer, SO_PRNG_BUFFER, &p->counter, sizeof(p->counter), p->seed, 64);
+            p->counter++;
+            p->head = 0;
+        }
+    }
+}
+
+static uint32_t prng_u32(so_prng *p)
+{
+    uint32_t r;
+    so_prng_generate(p, 4, &r);
+    return r;
+}
+
+/* std::uniform_int_distribution<uint64_t>(0, 2) over the 32-bit adapter (randomtostd.h) as libstdc++ 11 computes
+ * it: Lemire's method, product = word * 3, redraw while the low half is below 2^32 mod 3 = 1 */
+static uint64_t prng_uniform3(so_prng *p)
+{
+    uint64_t product = (uint64_t)prng_u32(p) * 3u;
+    uint32_t low = (uint32_t)product;
+    if (low < 3u)
+    {
+        uint32_t threshold = (uint32_t)(0u - 3u) % 3u;
+        while (low < threshold)
+        {
+            product = (uint64_t)prng_u32(p) * 3u;
+            low = (uint32_t)product;
+        }
+    }
+    return product >> 32;
+}
+
+/* util/rlwe.cpp:21-38 */
+void so_sample_poly_ternary(so_prng *p, const uint64_t *q, size_t limbs, size_t n, uint64_t *dest)
+{
+    for (size_t i = 0; i < n; i++)
+    {
+        uint64_t rand = prng_uniform3(p);
+        uint64_t flag = (uint64_t)(-(int64_t)(rand == 0));
+        for (size_t j = 0; j < limbs; j++)
+            dest[i + j * n] = rand + (flag & q[j]) - 1;
+    }
+}
+
+/* util/rlwe.cpp:66-101 */
+void so_sample_poly_cbd(so_prng *p, const uint64_t *q, size_t limbs, size_t n, uint64_t *dest)
+{
+    for (size_t i = 0; i < n; i++)
+    {
+        unsigned char x[6];
+        so_prng_generate(p, 6, x);
+        x[2] &= 0x1F;
+        x[5] &= 0x1F;
+        int32_t noise = __builtin_popcount(x[0]) + __builtin_popcount(x[1]) + __builtin_popcount(x[2]) -
+                        __builtin_popcount(x[3]) - __builtin_popcount(x[4]) - __builtin_popcount(x[5]);
+        uint64_t flag = (uint64_t)(-(int64_t)(noise < 0));
+        for (size_t j = 0; j < limbs; j++)
+            dest[i + j * n] = (uint64_t)(int64_t)noise + (flag & q[j]);
+    }
+}
+
+/* util/rlwe.cpp:103-131 */
+void so_sample_poly_uniform(so_prng *p, const uint64_t *q, size_t limbs, size_t n, uint64_t *dest)
+{
+    so_prng_generate(p, limbs * n * sizeof(uint64_t), dest);
+    for (size_t j = 0; j < limbs; j++)
+    {
+        so_modulus m;
+        so_modulus_init(&m, q[j]);
+        uint64_t max_random = 0xFFFFFFFFFFFFFFFFULL;
+        uint64_t max_multiple = max_random - so_barrett_reduce_64(max_random, &m) - 1;
+        for (size_t i = 0; i < n; i++)
+        {
+            uint64_t rand = dest[i + j * n];
+            while (rand >= max_multiple)
+                so_prng_generate(p, sizeof(rand), &rand);
+            dest[i + j * n] = so_barrett_reduce_64(rand, &m);
+        }
+    }
+}
+
+/* keygenerator.cpp:56-91: sk over all k key primes, NTT form */
+void so_seal_gen_secret_key(const so_context *c, const uint64_t factory_seed[8], uint64_t *sk)
+{
+    so_prng *p = so_prng_create(factory_seed);
+    so_sample_poly_ternary(p, c->primes, c->k, c->n, sk);
+    so_prng_destroy(p);
+    for (size_t i = 0; i < c->k; i++)
+        so_ntt_forward(sk + i * c->n, c->tables[i], 0);
+}
+
+/* util/rlwe.cpp:282-412 without save_seed: ct = 2 polys x L limbs */
+void so_seal_encrypt_zero_symmetric(const so_context *c, size_t L, const uint64_t *sk, const uint64_t factory_seed[8],
+                                    int ntt_form, uint64_t *ct)
+{
+    size_t n = c->n;
+    uint64_t *c0 = ct, *c1 = ct + L * n;
+    so_prng *bootstrap = so_prng_create(factory_seed);
+    uint64_t public_seed[8];
+    so_prng_generate(bootstrap, 64, public_seed);
+    so_prng *cprng = so_prng_create(public_seed);
+    so_sample_poly_uniform(cprng, c->primes, L, n, c1);
+    uint64_t *noise = (uint64_t *)malloc(sizeof(uint64_t) * L * n);
+    so_sample_poly_cbd(bootstrap, c->primes, L, n, noise);
+    for (size_t i = 0; i < L; i++)
+    {
+        const so_modulus *m = &c->mod[i];
+        so_dyadic_product_coeffmod(sk + i * n, c1 + i * n, n, m, c0 + i * n);
+        if (ntt_form)
+            so_ntt_forward(noise + i * n, c->tables[i], 0);
+        else
+            so_ntt_inverse(c0 + i * n, c->tables[i], 0);
+        if (c->scheme == SO_SCHEME_BGV)
+            so_multiply_poly_scalar_coeffmod(noise + i * n, n, c->plain_modulus, m, noise + i * n);
+        so_add_poly_coeffmod(noise + i * n, c0 + i * n, n, m, c0 + i * n);
+        so_negate_poly_coeffmod(c0 + i * n, n, m, c0 + i * n);
+    }
+    if (!ntt_form)
+        for (size_t i = 0; i < L; i++)
+            so_ntt_inverse(c1 + i * n, c->tables[i], 0);
+    free(noise);
+    so_prng_destroy(cprng);
+    so_prng_destroy(bootstrap);
+}
+
+/* util/rlwe.cpp:189-280 at the level with L limbs; pk = 2 polys x k limbs (key level, NTT form) */
+void so_seal_encrypt_zero_asymmetric(const so_context *c, size_t L, const uint64_t *pk, const uint64_t factory_seed[8],
+                                     int ntt_form, uint64_t *ct)
+{
+    size_t n = c->n, k = c->k;
+    so_prng *p = so_prng_create(factory_seed);
+    uint64_t *u = (uint64_t *)malloc(sizeof(uint64_t) * L * n);
+    so_sample_poly_ternary(p, c->primes, L, n, u);
+    for (size_t i = 0; i < L; i++)
+    {
+        so_ntt_forward(u + i * n, c->tables[i], 0);
+        for (size_t j = 0; j < 2; j++)
+        {
+            uint64_t *d = ct + (j * L + i) * n;
+            so_dyadic_product_coeffmod(u + i * n, pk + (j * k + i) * n, n, &c->mod[i], d);
+            if (!ntt_form)
+                so_ntt_inverse(d, c->tables[i], 0);
+        }
+    }
+    for (size_t j = 0; j < 2; j++)
+    {
+        so_sample_poly_cbd(p, c->primes, L, n, u);
+        for (size_t i = 0; i < L; i++)
+        {
+            uint64_t *e = u + i * n, *d = ct + (j * L + i) * n;
+            if (c->scheme == SO_SCHEME_BGV)
+            {
+                if (ntt_form)
+                    so_ntt_forward(e, c->tables[i], 1);
+                so_multiply_poly_scalar_coeffmod(e, n, c->plain_modulus, &c->mod[i], e);
+            }
+            else if (ntt_form)
+                so_ntt_forward(e, c->tables[i], 0);
+            so_add_poly_coeffmod(e, d, n, &c->mod[i], d);
+        }
+    }
+    free(u);
+    so_prng_destroy(p);
+}
+
+/* Encryptor::encrypt_zero_internal (encryptor.cpp:84-180): below the key level a public-key encryption is made one
+ * level up and switched down */
+void so_seal_encrypt_zero(so_context *c, size_t L, const uint64_t *pk, const uint64_t *sk, const uint64_t factory_seed[8],
+                          uint64_t *ct)
+{
+    int ntt_form = c->scheme != SO_SCHEME_BFV;
+    if (!pk)
+    {
+        so_seal_encrypt_zero_symmetric(c, L, sk, factory_seed, ntt_form, ct);
+        return;
+    }
+    if (L == c->k)
+    {
+        so_seal_encrypt_zero_asymmetric(c, L, pk, factory_seed, ntt_form, ct);
+        return;
+    }
+    uint64_t *tmp = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (L + 1) * c->n);
+    so_seal_encrypt_zero_asymmetric(c, L + 1, pk, factory_seed, ntt_form, tmp);
+    so_mod_switch_scale_to_next(c, L + 1, tmp, 2, ct);
+    free(tmp);
+}
+
+/* keygenerator.cpp:301-334 with the reference's generators; key layout [k-1][2][k][N] */
+void so_seal_gen_kswitch_key(const so_context *c, const uint64_t *sk, const uint64_t *new_key,
+                             const uint64_t factory_seed[8], uint64_t *key)
+{
+    size_t n = c->n, k = c->k, d = k - 1;
+    uint64_t *t = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    for (size_t J = 0; J < d; J++)
+    {
+        uint64_t *c0 = key + (J * 2) * k * n;
+        so_seal_encrypt_zero_symmetric(c, k, sk, factory_seed, 1, c0);
+        const so_modulus *m = &c->mod[J];
+        uint64_t factor = so_barrett_reduce_64(c->mod[k - 1].value, m);
+        so_multiply_poly_scalar_coeffmod(new_key + J * n, n, factor, m, t);
+        so_add_poly_coeffmod(c0 + J * n, t, n, m, c0 + J * n);
+    }
+    free(t);
+}
+
+void so_seal_gen_relin_key(const so_context *c, const uint64_t *sk, const uint64_t factory_seed[8], uint64_t *key)
+{
+    size_t n = c->n, k = c->k;
+    uint64_t *s2 = (uint64_t *)malloc(sizeof(uint64_t) * k * n);
+    for (size_t i = 0; i < k; i++)
+        so_dyadic_product_coeffmod(sk + i * n, sk + i * n, n, &c->mod[i], s2 + i * n);
+    so_seal_gen_kswitch_key(c, sk, s2, factory_seed, key);
+    free(s2);
+}
+
+void so_seal_gen_galois_key(const so_context *c, const uint64_t *sk, uint32_t elt, const uint64_t factory_seed[8],
+                            uint64_t *key)
+{
+    size_t n = c->n, k = c->k;
+    uint64_t *rs = (uint64_t *)malloc(sizeof(uint64_t) * k * n);
+    for (size_t i = 0; i < k; i++)
+        so_apply_galois_ntt(sk + i * n, c->log_n, elt, rs + i * n);
+    so_seal_gen_kswitch_key(c, sk, rs, factory_seed, key);
+    free(rs);
+}
+
+/* decryptor.cu:544-626: out (L limbs) = c0 + c1 s + ... in the form of the ciphertext */
+void so_seal_dot_product_ct_sk(const so_context *c, size_t L, const uint64_t *sk, const uint64_t *ct, size_t size,
+                               int ntt_form, uint64_t *out)
+{
+    size_t n = c->n;
+    uint64_t *t = (uint64_t *)malloc(sizeof(uint64_t) * n), *sp = (uint64_t *)malloc(sizeof(uint64_t) * n),
+             *acc = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    for (size_t i = 0; i < L; i++)
+    {
+        const so_modulus *m = &c->mod[i];
+        memset(acc, 0, sizeof(uint64_t) * n);
+        memcpy(sp, sk + i * n, sizeof(uint64_t) * n);
+        for (size_t p = 1; p < size; p++)
+        {
+            memcpy(t, ct + (p * L + i) * n, sizeof(uint64_t) * n);
+            if (!ntt_form)
+                so_ntt_forward(t, c->tables[i], 1);
+            so_dyadic_product_coeffmod(t, sp, n, m, t);
+            so_add_poly_coeffmod(acc, t, n, m, acc);
+            so_dyadic_product_coeffmod(sp, sk + i * n, n, m, sp);
+        }
+        if (!ntt_form)
+            so_ntt_inverse(acc, c->tables[i], 0);
+        so_add_poly_coeffmod(acc, ct + i * n, n, m, out + i * n);
+    }
+    free(t);
+    free(sp);
+    free(acc);
+}

@@ -169,6 +169,35 @@ void so_decrypt_phase(const so_context *c, size_t L, const uint64_t *sk_ntt, con
                       int ntt_form, uint64_t *phase);
 void so_fill_uniform(const so_context *c, size_t L, size_t polys, uint64_t seed, uint64_t *out);
 
+/* ---- the reference's own randomness and key material: Blake2xb PRNG (randomgen.cpp:176-211),
+ * samplers (util/rlwe.cpp:21-131), KeyGenerator (keygenerator.cpp:56-363), encrypt_zero_* (util/rlwe.cpp:189-412),
+ * Encryptor::encrypt_zero_internal (encryptor.cpp:84-180), Decryptor::dot_product_ct_sk_array (decryptor.cu:544-626).
+ * factory_seed = the default seed of a Blake2xbPRNGFactory: every generator created starts from it. ---- */
+typedef struct so_prng so_prng;
+int so_blake2b(void *out, size_t outlen, const void *in, size_t inlen, const void *key, size_t keylen);
+int so_blake2xb(void *out, size_t outlen, const void *in, size_t inlen, const void *key, size_t keylen);
+so_prng *so_prng_create(const uint64_t seed[8]);
+void so_prng_destroy(so_prng *p);
+void so_prng_generate(so_prng *p, size_t count, void *dest);
+void so_sample_poly_ternary(so_prng *p, const uint64_t *q, size_t limbs, size_t n, uint64_t *dest);
+void so_sample_poly_cbd(so_prng *p, const uint64_t *q, size_t limbs, size_t n, uint64_t *dest);
+void so_sample_poly_uniform(so_prng *p, const uint64_t *q, size_t limbs, size_t n, uint64_t *dest);
+void so_seal_gen_secret_key(const so_context *c, const uint64_t factory_seed[8], uint64_t *sk /* k limbs, NTT */);
+void so_seal_encrypt_zero_symmetric(const so_context *c, size_t L, const uint64_t *sk, const uint64_t factory_seed[8],
+                                    int ntt_form, uint64_t *ct /* 2 x L x N */);
+void so_seal_encrypt_zero_asymmetric(const so_context *c, size_t L, const uint64_t *pk /* 2 x k x N */,
+                                     const uint64_t factory_seed[8], int ntt_form, uint64_t *ct);
+/* pk == NULL: symmetric with sk */
+void so_seal_encrypt_zero(so_context *c, size_t L, const uint64_t *pk, const uint64_t *sk, const uint64_t factory_seed[8],
+                          uint64_t *ct);
+void so_seal_gen_kswitch_key(const so_context *c, const uint64_t *sk, const uint64_t *new_key,
+                             const uint64_t factory_seed[8], uint64_t *key /* [k-1][2][k][N] */);
+void so_seal_gen_relin_key(const so_context *c, const uint64_t *sk, const uint64_t factory_seed[8], uint64_t *key);
+void so_seal_gen_galois_key(const so_context *c, const uint64_t *sk, uint32_t elt, const uint64_t factory_seed[8],
+                            uint64_t *key);
+void so_seal_dot_product_ct_sk(const so_context *c, size_t L, const uint64_t *sk, const uint64_t *ct, size_t size,
+                               int ntt_form, uint64_t *out /* L limbs */);
+
 #ifdef __cplusplus
 }
 #endif

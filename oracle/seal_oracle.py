@@ -129,6 +129,22 @@ def lib() -> C.CDLL:
             "so_encrypt_symmetric": (None, [vp, sz, u64p, u64p, u64, C.c_int, u64p]),
             "so_decrypt_phase": (None, [vp, sz, u64p, u64p, sz, C.c_int, u64p]),
             "so_fill_uniform": (None, [vp, sz, sz, u64, u64p]),
+            "so_blake2b": (C.c_int, [vp, sz, vp, sz, vp, sz]),
+            "so_blake2xb": (C.c_int, [vp, sz, vp, sz, vp, sz]),
+            "so_prng_create": (vp, [u64p]),
+            "so_prng_destroy": (None, [vp]),
+            "so_prng_generate": (None, [vp, sz, vp]),
+            "so_sample_poly_ternary": (None, [vp, u64p, sz, sz, u64p]),
+            "so_sample_poly_cbd": (None, [vp, u64p, sz, sz, u64p]),
+            "so_sample_poly_uniform": (None, [vp, u64p, sz, sz, u64p]),
+            "so_seal_gen_secret_key": (None, [vp, u64p, u64p]),
+            "so_seal_encrypt_zero_symmetric": (None, [vp, sz, u64p, u64p, C.c_int, u64p]),
+            "so_seal_encrypt_zero_asymmetric": (None, [vp, sz, u64p, u64p, C.c_int, u64p]),
+            "so_seal_encrypt_zero": (None, [vp, sz, u64p, u64p, u64p, u64p]),
+            "so_seal_gen_kswitch_key": (None, [vp, u64p, u64p, u64p, u64p]),
+            "so_seal_gen_relin_key": (None, [vp, u64p, u64p, u64p]),
+            "so_seal_gen_galois_key": (None, [vp, u64p, C.c_uint32, u64p, u64p]),
+            "so_seal_dot_product_ct_sk": (None, [vp, sz, u64p, u64p, sz, C.c_int, u64p]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -433,3 +449,80 @@ class Context:
         out = np.zeros((L, self.n), dtype=np.uint64)
         lib().so_decrypt_phase(self.h, L, ptr(sk), ptr(ct), size, int(ntt_form), ptr(out))
         return out
+
+    # -- the reference's own randomness; seed = 8 words = a Blake2xbPRNGFactory default seed ----
+    def seal_secret_key(self, seed) -> np.ndarray:
+        sk = np.zeros((self.k, self.n), dtype=np.uint64)
+        lib().so_seal_gen_secret_key(self.h, ptr(arr(seed)), ptr(sk))
+        return sk
+
+    def seal_public_key(self, sk, seed) -> np.ndarray:
+        pk = np.zeros((2, self.k, self.n), dtype=np.uint64)
+        lib().so_seal_encrypt_zero_symmetric(self.h, self.k, ptr(arr(sk)), ptr(arr(seed)), 1, ptr(pk))
+        return pk
+
+    def seal_encrypt_zero(self, L: int, seed, pk=None, sk=None) -> np.ndarray:
+        ct = np.zeros((2, L, self.n), dtype=np.uint64)
+        lib().so_seal_encrypt_zero(self.h, L, ptr(arr(pk)) if pk is not None else None,
+                                   ptr(arr(sk)) if sk is not None else None, ptr(arr(seed)), ptr(ct))
+        return ct
+
+    def seal_relin_key(self, sk, seed) -> np.ndarray:
+        key = np.zeros((self.k - 1, 2, self.k, self.n), dtype=np.uint64)
+        lib().so_seal_gen_relin_key(self.h, ptr(arr(sk)), ptr(arr(seed)), ptr(key))
+        return key
+
+    def seal_galois_key(self, sk, elt: int, seed) -> np.ndarray:
+        key = np.zeros((self.k - 1, 2, self.k, self.n), dtype=np.uint64)
+        lib().so_seal_gen_galois_key(self.h, ptr(arr(sk)), elt, ptr(arr(seed)), ptr(key))
+        return key
+
+    def seal_dot_product(self, sk, ct: np.ndarray, ntt_form: bool) -> np.ndarray:
+        size, L = ct.shape[0], ct.shape[1]
+        out = np.zeros((L, self.n), dtype=np.uint64)
+        lib().so_seal_dot_product_ct_sk(self.h, L, ptr(arr(sk)), ptr(arr(ct)), size, int(ntt_form), ptr(out))
+        return out
+
+
+class PRNG:
+    """Blake2xbPRNG (randomgen.cpp:201-211)"""
+
+    def __init__(self, seed):
+        self.h = lib().so_prng_create(ptr(arr(seed)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().so_prng_destroy(self.h)
+            self.h = None
+
+    def generate(self, count: int) -> bytes:
+        buf = C.create_string_buffer(count)
+        lib().so_prng_generate(self.h, count, buf)
+        return buf.raw
+
+    def _sample(self, fn, q, n):
+        q = arr(q)
+        out = np.zeros((len(q), n), dtype=np.uint64)
+        fn(self.h, ptr(q), len(q), n, ptr(out))
+        return out
+
+    def ternary(self, q, n):
+        return self._sample(lib().so_sample_poly_ternary, q, n)
+
+    def cbd(self, q, n):
+        return self._sample(lib().so_sample_poly_cbd, q, n)
+
+    def uniform(self, q, n):
+        return self._sample(lib().so_sample_poly_uniform, q, n)
+
+
+def blake2b(data: bytes, outlen: int = 64, key: bytes = b"") -> bytes:
+    out = C.create_string_buffer(outlen)
+    assert lib().so_blake2b(out, outlen, data, len(data), key if key else None, len(key)) == 0
+    return out.raw
+
+
+def blake2xb(data: bytes, outlen: int, key: bytes = b"") -> bytes:
+    out = C.create_string_buffer(outlen)
+    assert lib().so_blake2xb(out, outlen, data, len(data), key if key else None, len(key)) == 0
+    return out.raw

@@ -2,7 +2,7 @@
 // seal::Evaluator (native/tests/seal/evaluator.cpp:3354-3623: multiply, relinearize, rescale, rotate), but
 // bit-exact against the CPU oracle instead of decrypt-and-compare with a tolerance.  Needs a GPU; built by
 // `make facade_test`, run by tests/test_gpu_facade.py.  Test infrastructure: links oracle/libseal_oracle.so.
-#include "../../cat_amd/host/seal_hip.hpp"
+#include "../../cat_amd/host/seal_hip_crypto.hpp"
 #include "../../oracle/seal_oracle.h"
 
 #include <cstdio>
@@ -335,6 +335,178 @@ static void test_bgv()
     so_context_destroy(oc);
 }
 
+// KeyGenerator / Encryptor / Decryptor of the facade with a fixed-seed Blake2xbPRNGFactory against
+// the oracle's restatement of keygenerator.cpp, util/rlwe.cpp, encryptor.cpp and decryptor.cu with the same seed:
+// identical key and ciphertext words, then the Evaluator pipeline on them, then decryption.
+static void test_crypto(scheme_type scheme)
+{
+    const int log_n = 12;
+    const size_t n = 4096;
+    const int bits[4] = { 50, 40, 40, 50 };
+    const uint64_t t = scheme == scheme_type::ckks ? 0 : 65537;
+    vec primes(4);
+    EXPECT(so_coeff_modulus_create(n, bits, 4, primes.data()) == 0);
+    const size_t k = 4;
+    const int so_scheme = scheme == scheme_type::ckks ? SO_SCHEME_CKKS : scheme == scheme_type::bfv ? SO_SCHEME_BFV : SO_SCHEME_BGV;
+    so_context *oc = so_context_create(log_n, primes.data(), k, so_scheme, t);
+    const bool ntt = scheme != scheme_type::bfv;
+    const prng_seed_type seed = { 101, 102, 103, 104, 105, 106, 107, 108 };
+
+    EncryptionParameters parms(scheme);
+    parms.set_poly_modulus_degree(n);
+    parms.set_coeff_modulus(primes);
+    parms.set_plain_modulus(t);
+    parms.set_random_generator(std::make_shared<Blake2xbPRNGFactory>(seed));
+    SEALContext context(parms);
+
+    KeyGenerator keygen(context);
+    vec sk(k * n);
+    so_seal_gen_secret_key(oc, seed.data(), sk.data());
+    EXPECT(keygen.secret_key().to_cpu() == sk);
+
+    PublicKey public_key;
+    keygen.create_public_key(public_key);
+    vec pk(2 * k * n);
+    so_seal_encrypt_zero_symmetric(oc, k, sk.data(), seed.data(), 1, pk.data());
+    EXPECT(public_key.data().coeff_modulus_size() == k && public_key.data().is_ntt_form() && public_key.data().to_cpu() == pk);
+
+    RelinKeys relin_keys(context);
+    keygen.create_relin_keys(relin_keys);
+    vec rk((k - 1) * 2 * k * n);
+    so_seal_gen_relin_key(oc, sk.data(), seed.data(), rk.data());
+    EXPECT(relin_keys.has_key(2) && relin_keys.key_to_cpu(0) == rk);
+
+    GaloisKeys galois_keys(context);
+    keygen.create_galois_keys(std::vector<int>{ 1 }, galois_keys);
+    const uint32_t elt = so_galois_elt_from_step(log_n, 1);
+    vec gk(rk.size());
+    so_seal_gen_galois_key(oc, sk.data(), elt, seed.data(), gk.data());
+    EXPECT(galois_keys.has_key(elt) && galois_keys.key_to_cpu(GaloisKeys::get_index(elt)) == gk);
+
+    // a KeyGenerator built from an existing secret key makes the same keys (keygenerator.cpp:27-54)
+    {
+        KeyGenerator again(context, SecretKey(context, sk.data()));
+        PublicKey pk2;
+        again.create_public_key(pk2);
+        EXPECT(pk2.data().to_cpu() == pk);
+    }
+
+    Encryptor encryptor(context, public_key, keygen.secret_key());
+    Decryptor decryptor(context, keygen.secret_key());
+    for (size_t L = k; L >= 2; --L)
+    {
+        // public-key encryptions below the key level are made one level up and switched down (encryptor.cpp:124-166)
+        vec e(2 * L * n), ph(L * n);
+        Ciphertext ct;
+        so_seal_encrypt_zero(oc, L, pk.data(), nullptr, seed.data(), e.data());
+        encryptor.encrypt_zero(L, ct);
+        EXPECT(ct.coeff_modulus_size() == L && ct.is_ntt_form() == ntt && ct.to_cpu() == e);
+        so_seal_encrypt_zero(oc, L, nullptr, sk.data(), seed.data(), e.data());
+        encryptor.encrypt_zero_symmetric(L, ct);
+        EXPECT(ct.to_cpu() == e);
+        // the phase c0 + c1 s (decryptor.cu:560-591)
+        so_seal_dot_product_ct_sk(oc, L, sk.data(), e.data(), 2, ntt, ph.data());
+        seal::detail::DeviceWords d_ph(context.handle(), L * n);
+        decryptor.dot_product_ct_sk_array(ct, d_ph.get());
+        EXPECT(d_ph.to_cpu() == ph);
+    }
+    {
+        Encryptor no_keys(context, keygen.secret_key());
+        Ciphertext ct;
+        EXPECT(throws<std::logic_error>([&] { no_keys.encrypt_zero(ct); })); // "public key is not set"
+    }
+
+    if (scheme != scheme_type::ckks)
+    {
+        // size-3 phase in coefficient (BFV) / NTT (BGV) form: c0 + c1 s + c2 s^2 (decryptor.cu:592-625)
+        const size_t L = 3;
+        vec x = uniform(oc, L, 3, n, 40), ph(L * n);
+        Ciphertext ct(context, L, 3);
+        ct.upload(x.data());
+        ct.is_ntt_form() = ntt;
+        so_seal_dot_product_ct_sk(oc, L, sk.data(), x.data(), 3, ntt, ph.data());
+        seal::detail::DeviceWords d_ph(context.handle(), L * n);
+        decryptor.dot_product_ct_sk_array(ct, d_ph.get());
+        EXPECT(d_ph.to_cpu() == ph);
+        Plaintext plain(context, L);
+        EXPECT(throws<std::logic_error>([&] { decryptor.decrypt(ct, plain); }));
+        so_context_destroy(oc);
+        return;
+    }
+
+    // CKKS end to end: encrypt two plaintexts, multiply, relinearize, rescale, rotate, decrypt
+    const size_t L = 3;
+    const double delta = std::pow(2.0, 30);
+    auto make_plain = [&](uint64_t mseed, vec &host) {
+        host.assign(L * n, 0);
+        for (size_t i = 0; i < n; ++i)
+        {
+            const uint64_t m = (mseed * 2654435761ULL + i * 40503ULL) % 97; // small message coefficients
+            for (size_t j = 0; j < L; ++j)
+                host[j * n + i] = (m << 30) % primes[j];
+        }
+        for (size_t j = 0; j < L; ++j)
+            so_ntt_forward(&host[j * n], so_context_tables(oc, j), 0);
+    };
+    vec p1, p2;
+    make_plain(1, p1);
+    make_plain(2, p2);
+    Plaintext plain1(context, L), plain2(context, L);
+    plain1.upload(p1.data());
+    plain2.upload(p2.data());
+    plain1.scale() = plain2.scale() = delta;
+    Ciphertext c1, c2;
+    encryptor.encrypt(plain1, c1);
+    encryptor.encrypt_symmetric(plain2, c2);
+    vec e1(2 * L * n), e2(2 * L * n);
+    so_seal_encrypt_zero(oc, L, pk.data(), nullptr, seed.data(), e1.data());
+    so_seal_encrypt_zero(oc, L, nullptr, sk.data(), seed.data(), e2.data());
+    for (size_t j = 0; j < L; ++j)
+    {
+        so_add_poly_coeffmod(&e1[j * n], &p1[j * n], n, &so_context_tables(oc, j)->mod, &e1[j * n]);
+        so_add_poly_coeffmod(&e2[j * n], &p2[j * n], n, &so_context_tables(oc, j)->mod, &e2[j * n]);
+    }
+    EXPECT(c1.to_cpu() == e1 && c2.to_cpu() == e2 && c1.scale() == delta);
+
+    // decrypt(encrypt(m)) is m up to the fresh noise, and equals the oracle's phase word for word
+    {
+        Plaintext back(context, L);
+        decryptor.decrypt(c1, back);
+        vec ph(L * n);
+        so_seal_dot_product_ct_sk(oc, L, sk.data(), e1.data(), 2, 1, ph.data());
+        EXPECT(back.to_cpu() == ph && back.scale() == delta);
+        so_ntt_inverse(ph.data(), so_context_tables(oc, 0), 0);
+        bool close = true;
+        for (size_t i = 0; i < n; ++i)
+        {
+            const uint64_t m = (1 * 2654435761ULL + i * 40503ULL) % 97;
+            const int64_t v = ph[i] > primes[0] / 2 ? (int64_t)ph[i] - (int64_t)primes[0] : (int64_t)ph[i];
+            close = close && std::llabs(v - (int64_t)(m << 30)) < (1 << 20);
+        }
+        EXPECT(close);
+    }
+
+    Evaluator evaluator(context);
+    vec exp3(3 * L * n, 0);
+    std::memcpy(exp3.data(), e1.data(), e1.size() * 8);
+    so_ckks_multiply(oc, L, exp3.data(), e2.data());
+    so_relinearize(oc, L, exp3.data(), rk.data());
+    vec exp2(exp3.begin(), exp3.begin() + 2 * L * n), expr(2 * (L - 1) * n);
+    so_mod_switch_scale_to_next(oc, L, exp2.data(), 2, expr.data());
+    so_apply_galois_inplace(oc, L - 1, expr.data(), elt, gk.data());
+    evaluator.multiply_inplace(c1, c2);
+    evaluator.relinearize_inplace(c1, relin_keys);
+    evaluator.rescale_to_next_inplace(c1);
+    evaluator.rotate_vector_inplace(c1, 1, galois_keys);
+    EXPECT(c1.to_cpu() == expr);
+    Plaintext result(context, L - 1);
+    decryptor.decrypt(c1, result);
+    vec ph((L - 1) * n);
+    so_seal_dot_product_ct_sk(oc, L - 1, sk.data(), expr.data(), 2, 1, ph.data());
+    EXPECT(result.to_cpu() == ph && result.scale() == delta * delta / (double)primes[L - 1]);
+    so_context_destroy(oc);
+}
+
 int main()
 {
     try
@@ -343,6 +515,9 @@ int main()
         test_ckks();
         test_bfv();
         test_bgv();
+        test_crypto(scheme_type::ckks);
+        test_crypto(scheme_type::bfv);
+        test_crypto(scheme_type::bgv);
     }
     catch (const std::exception &e)
     {
