@@ -5,7 +5,7 @@
 //
 // BLAKE2b is written from RFC 7693 and BLAKE2Xb from the BLAKE2X specification (the reference vendors the BLAKE2
 // authors' C files, util/blake2b.c and util/blake2xb.c; tests/test_random_keys.py checks this file's stream against
-// those files compiled as they lie, oracle/_ref).
+// those files compiled as they lie).
 #pragma once
 
 #include <algorithm>
