@@ -29,7 +29,7 @@
 #include <utility>
 #include <vector>
 
-#include "seal_hip_random.hpp"
+#include "seal_hip_serialization.hpp" // brings seal_hip_random.hpp
 
 namespace seal
 {
@@ -158,6 +158,30 @@ namespace seal
         bool using_keyswitching() const noexcept
         {
             return key_modulus_size() > 1;
+        }
+        // parms_id of the level with L limbs (the hash of that level's EncryptionParameters, encryptionparams.cpp:124-158;
+        // chain: context.cu:607-637, 726-765) and the way back; 0 = no such level
+        parms_id_type parms_id(std::size_t coeff_modulus_size) const
+        {
+            if (coeff_modulus_size == 0 || coeff_modulus_size > key_modulus_size())
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            return util::compute_parms_id((std::uint8_t)parms_.scheme(), parms_.poly_modulus_degree(),
+                                          parms_.coeff_modulus().data(), coeff_modulus_size, parms_.plain_modulus());
+        }
+        parms_id_type key_parms_id() const
+        {
+            return parms_id(key_modulus_size());
+        }
+        parms_id_type first_parms_id() const
+        {
+            return parms_id(first_level_size());
+        }
+        std::size_t level_of(const parms_id_type &id) const
+        {
+            for (std::size_t L = key_modulus_size(); L >= 1; --L)
+                if (parms_id(L) == id)
+                    return L;
+            return 0;
         }
 
     private:
@@ -342,6 +366,95 @@ namespace seal
         {
             return ctx_.get();
         }
+        parms_id_type parms_id() const
+        {
+            return ctx_ && L_ ? ctx_->parms_id(L_) : parms_id_zero;
+        }
+
+        // Ciphertext::save_members / save_size (ciphertext.cpp:188-286), uncompressed: parms_id, NTT flag, size, N, limbs,
+        // scale, correction factor, then the data as a DynArray -- or, when the second polynomial starts with the seed
+        // marker (util/rlwe.cpp:404-411), the first polynomial and the generator info
+        std::streamoff save_size(bool seeded = false) const
+        {
+            const std::size_t members = sizeof(parms_id_type) + 1 + 4 * 8 + 8;
+            return static_cast<std::streamoff>(sizeof(Serialization::SEALHeader) + members) +
+                   (seeded ? util::dynarray_save_size(words() / 2) + UniformRandomGeneratorInfo::SaveSize()
+                           : util::dynarray_save_size(words()));
+        }
+        std::streamoff save(std::ostream &stream) const
+        {
+            const std::vector<std::uint64_t> host = to_cpu();
+            const bool seeded = size_ == 2 && !host.empty() && host[L_ * n_] == 0xFFFFFFFFFFFFFFFFULL;
+            return Serialization::Save(
+                [&](std::ostream &s) {
+                    util::write_pod(s, parms_id());
+                    util::write_pod<std::uint8_t>(s, is_ntt_form_ ? 1 : 0);
+                    util::write_pod<std::uint64_t>(s, size_);
+                    util::write_pod<std::uint64_t>(s, n_);
+                    util::write_pod<std::uint64_t>(s, L_);
+                    util::write_pod(s, scale_);
+                    util::write_pod(s, correction_factor_);
+                    if (seeded)
+                    {
+                        util::dynarray_save(s, host.data(), host.size() / 2);
+                        // the info was stored as a serialized object after the marker word: copy it through
+                        s.write(reinterpret_cast<const char *>(host.data() + L_ * n_ + 1),
+                                static_cast<std::streamsize>(UniformRandomGeneratorInfo::SaveSize()));
+                    }
+                    else
+                        util::dynarray_save(s, host.data(), host.size());
+                },
+                save_size(seeded), stream);
+        }
+        // Ciphertext::load_members (ciphertext.cpp:288-400): metadata checked against the context, the data bounded by
+        // the size the metadata promises, a seeded ciphertext expanded with the generator it names (:153-186)
+        std::streamoff load(const SEALContext &context, std::istream &stream)
+        {
+            Ciphertext fresh;
+            const std::streamoff in_size = Serialization::Load(
+                [&](std::istream &s, SEALVersion version) {
+                    const parms_id_type id = util::read_pod<parms_id_type>(s);
+                    const std::uint8_t ntt = util::read_pod<std::uint8_t>(s);
+                    const std::uint64_t size64 = util::read_pod<std::uint64_t>(s);
+                    const std::uint64_t n64 = util::read_pod<std::uint64_t>(s);
+                    const std::uint64_t L64 = util::read_pod<std::uint64_t>(s);
+                    const double scale = util::read_pod<double>(s);
+                    std::uint64_t correction_factor = 1;
+                    if (version.major == 4)
+                        correction_factor = util::read_pod<std::uint64_t>(s);
+                    // is_metadata_valid_for(..., allow_pure_key_levels = true), valcheck.cpp
+                    const std::size_t L = context.level_of(id);
+                    if (!L || n64 != context.poly_modulus_degree() || L64 != L || size64 < 2 || size64 > 6)
+                        throw std::logic_error("ciphertext data is invalid");
+                    const std::size_t total = (std::size_t)size64 * L * (std::size_t)n64;
+                    std::vector<std::uint64_t> data = util::dynarray_load(s, total);
+                    if (data.size() == L * n64 && size64 == 2)
+                    {
+                        UniformRandomGeneratorInfo info;
+                        if (version.major == 4 || (version.major == 3 && version.minor >= 6))
+                            info.load(s);
+                        else
+                            throw std::logic_error("incompatible version"); // the 3.4 / 3.5 samplers are not restated
+                        auto prng = info.make_prng();
+                        if (!prng)
+                            throw std::logic_error("unsupported prng_type");
+                        data.resize(total);
+                        const auto &q = context.parms().coeff_modulus();
+                        util::sample_poly_uniform(prng, std::vector<std::uint64_t>(q.begin(), q.begin() + (std::ptrdiff_t)L),
+                                                  (std::size_t)n64, data.data() + L * n64);
+                    }
+                    if (data.size() != total) // is_buffer_valid
+                        throw std::logic_error("ciphertext data is invalid");
+                    fresh.resize(context, L, (std::size_t)size64);
+                    fresh.upload(data.data());
+                    fresh.is_ntt_form_ = ntt != 0;
+                    fresh.scale_ = scale;
+                    fresh.correction_factor_ = correction_factor;
+                },
+                stream);
+            *this = std::move(fresh);
+            return in_size;
+        }
 
     private:
         void reserve_words(std::size_t want)
@@ -425,6 +538,44 @@ namespace seal
         {
             return buf_.scale();
         }
+        // Plaintext::save_members / load_members (plaintext.cpp:207-290) for an NTT-form plaintext: parms_id of its
+        // level, coeff_count = limbs x N, scale, data
+        std::streamoff save(std::ostream &stream) const
+        {
+            const std::vector<std::uint64_t> host = to_cpu();
+            return Serialization::Save(
+                [&](std::ostream &s) {
+                    util::write_pod(s, buf_.parms_id());
+                    util::write_pod<std::uint64_t>(s, host.size());
+                    util::write_pod(s, buf_.scale());
+                    util::dynarray_save(s, host.data(), host.size());
+                },
+                static_cast<std::streamoff>(sizeof(Serialization::SEALHeader) + sizeof(parms_id_type) + 16) +
+                    util::dynarray_save_size(host.size()),
+                stream);
+        }
+        std::streamoff load(const SEALContext &context, std::istream &stream)
+        {
+            return Serialization::Load(
+                [&](std::istream &s, SEALVersion) {
+                    const parms_id_type id = util::read_pod<parms_id_type>(s);
+                    const std::uint64_t coeff_count = util::read_pod<std::uint64_t>(s);
+                    const double scale = util::read_pod<double>(s);
+                    const std::size_t L = context.level_of(id);
+                    if (!L) // parms_id_zero marks a coefficient-form (BFV/BGV) plaintext, which has no device form here
+                        throw std::logic_error("unsupported: only NTT-form plaintexts are device-resident");
+                    if (coeff_count != L * context.poly_modulus_degree())
+                        throw std::logic_error("plaintext data is invalid");
+                    const std::vector<std::uint64_t> data = util::dynarray_load(s, (std::size_t)coeff_count);
+                    if (data.size() != coeff_count)
+                        throw std::logic_error("plaintext data is invalid");
+                    Plaintext fresh(context, L);
+                    fresh.upload(data.data());
+                    fresh.scale() = scale;
+                    *this = std::move(fresh);
+                },
+                stream);
+        }
 
     private:
         Ciphertext buf_;
@@ -439,7 +590,7 @@ namespace seal
         {}
         KSwitchKeys(const KSwitchKeys &) = delete;
         KSwitchKeys &operator=(const KSwitchKeys &) = delete;
-        ~KSwitchKeys()
+        virtual ~KSwitchKeys()
         {
             for (auto *p : keys_)
                 if (p)
@@ -498,7 +649,86 @@ namespace seal
             return c;
         }
 
+        // KSwitchKeys::save_members / load_members (kswitchkeys.cpp:42-160): key-level parms_id, the number of entries,
+        // then per entry the number of PublicKeys (0 = absent) and each PublicKey = a size-2 key-level NTT-form
+        // Ciphertext object.  `entries` is keys_.size() of the reference: the key count for RelinKeys, N for GaloisKeys
+        // (keygenerator.cpp:188).
+        std::streamoff save(std::ostream &stream) const
+        {
+            const std::size_t k = ctx_->key_modulus_size(), n = ctx_->poly_modulus_degree(), entries = saved_entries();
+            Ciphertext pk(*ctx_, k, 2);
+            pk.is_ntt_form() = true;
+            std::streamoff raw = static_cast<std::streamoff>(sizeof(Serialization::SEALHeader) + sizeof(parms_id_type) + 8 + 8 * entries);
+            for (std::size_t i = 0; i < entries; ++i)
+                if (has_index(i))
+                    raw += static_cast<std::streamoff>(k - 1) * pk.save_size();
+            return Serialization::Save(
+                [&](std::ostream &s) {
+                    util::write_pod(s, ctx_->key_parms_id());
+                    util::write_pod<std::uint64_t>(s, entries);
+                    for (std::size_t i = 0; i < entries; ++i)
+                    {
+                        util::write_pod<std::uint64_t>(s, has_index(i) ? k - 1 : 0);
+                        if (!has_index(i))
+                            continue;
+                        const std::vector<std::uint64_t> host = key_to_cpu(i);
+                        for (std::size_t j = 0; j + 1 < k; ++j)
+                        {
+                            pk.upload(host.data() + j * 2 * k * n);
+                            pk.save(s);
+                        }
+                    }
+                },
+                raw, stream);
+        }
+        std::streamoff load(const SEALContext &context, std::istream &stream)
+        {
+            if (context.handle() != ctx_->handle())
+                throw std::invalid_argument("encryption parameters are not set correctly");
+            const std::size_t k = ctx_->key_modulus_size(), n = ctx_->poly_modulus_degree();
+            std::vector<std::vector<std::uint64_t>> loaded;
+            const std::streamoff in_size = Serialization::Load(
+                [&](std::istream &s, SEALVersion) {
+                    if (util::read_pod<parms_id_type>(s) != ctx_->key_parms_id())
+                        throw std::logic_error("KSwitchKeys data is invalid");
+                    const std::uint64_t dim1 = util::read_pod<std::uint64_t>(s);
+                    if (dim1 > n) // SEAL_CIPHERTEXT_SIZE_MAX - 2 for RelinKeys, N for GaloisKeys
+                        throw std::logic_error("KSwitchKeys data is invalid");
+                    loaded.resize((std::size_t)dim1);
+                    for (std::uint64_t i = 0; i < dim1; ++i)
+                    {
+                        const std::uint64_t dim2 = util::read_pod<std::uint64_t>(s);
+                        if (dim2 != 0 && dim2 != k - 1)
+                            throw std::logic_error("KSwitchKeys data is invalid");
+                        for (std::uint64_t j = 0; j < dim2; ++j)
+                        {
+                            Ciphertext pk;
+                            pk.load(context, s);
+                            if (pk.size() != 2 || pk.coeff_modulus_size() != k || !pk.is_ntt_form())
+                                throw std::logic_error("PublicKey data is invalid");
+                            const std::vector<std::uint64_t> w = pk.to_cpu();
+                            loaded[(std::size_t)i].insert(loaded[(std::size_t)i].end(), w.begin(), w.end());
+                        }
+                    }
+                },
+                stream);
+            for (auto *p : keys_)
+                if (p)
+                    cat_free(ctx_->handle(), p);
+            keys_.assign(loaded.size(), nullptr);
+            for (std::size_t i = 0; i < loaded.size(); ++i)
+                if (!loaded[i].empty())
+                    set_key(i, loaded[i].data());
+            return in_size;
+        }
+
     protected:
+        // keys_.size() as the reference would have it
+        virtual std::size_t saved_entries() const
+        {
+            return keys_.size();
+        }
+
         std::shared_ptr<SEALContext> ctx_;
         std::vector<std::uint64_t *> keys_;
     };
@@ -534,6 +764,12 @@ namespace seal
         bool has_key(std::uint32_t galois_elt) const
         {
             return has_index(get_index(galois_elt));
+        }
+
+    protected:
+        std::size_t saved_entries() const override // galois_keys.data().resize(coeff_count), keygenerator.cpp:188
+        {
+            return ctx_->poly_modulus_degree();
         }
     };
 

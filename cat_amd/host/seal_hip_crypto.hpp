@@ -9,7 +9,7 @@
 // public-key encryption) runs on the device through the C ABI.  A level is named by its limb count L as in
 // seal_hip.hpp; the key level has all k primes.
 //
-// Not restated: seeded (save_seed) ciphertexts, which belong to serialization (row f3); plaintext encoding and the
+// Not restated: plaintext encoding and the
 // BFV/BGV plaintext lift (`encrypt(plain)` is the CKKS branch; BFV/BGV callers use encrypt_zero and the phase);
 // the RNS tail of BFV/BGV decryption (RNSTool::decrypt_scale_and_round / decrypt_modt, out of scope in SURVEY
 // section 2) -- Decryptor exposes the phase c0 + c1 s + ... of any scheme and finishes CKKS, whose plaintext IS
@@ -17,6 +17,8 @@
 #pragma once
 
 #include "seal_hip.hpp"
+
+#include <sstream>
 
 namespace seal
 {
@@ -103,6 +105,44 @@ namespace seal
         {
             return (bool)data_;
         }
+        // SecretKey::save / unsafe_load (secretkey.cuh:140-260): the key is kept as a Plaintext at the key level --
+        // key parms_id, coeff_count = k N, scale 1.0, data (plaintext.cpp:207-233)
+        std::streamoff save(const SEALContext &context, std::ostream &stream) const
+        {
+            const std::vector<std::uint64_t> host = to_cpu();
+            return Serialization::Save(
+                [&](std::ostream &s) {
+                    util::write_pod(s, context.key_parms_id());
+                    util::write_pod<std::uint64_t>(s, host.size());
+                    util::write_pod<double>(s, 1.0);
+                    util::dynarray_save(s, host.data(), host.size());
+                },
+                static_cast<std::streamoff>(sizeof(Serialization::SEALHeader) + sizeof(parms_id_type) + 16) +
+                    util::dynarray_save_size(host.size()),
+                stream);
+        }
+        std::streamoff load(const SEALContext &context, std::istream &stream)
+        {
+            return Serialization::Load(
+                [&](std::istream &s, SEALVersion) {
+                    const parms_id_type id = util::read_pod<parms_id_type>(s);
+                    const std::uint64_t coeff_count = util::read_pod<std::uint64_t>(s);
+                    (void)util::read_pod<double>(s);
+                    const std::size_t words = context.key_modulus_size() * context.poly_modulus_degree();
+                    if (id != context.key_parms_id() || coeff_count != words) // is_valid_for(SecretKey), valcheck.cpp
+                        throw std::logic_error("SecretKey data is invalid");
+                    const std::vector<std::uint64_t> data = util::dynarray_load(s, words);
+                    if (data.size() != words)
+                        throw std::logic_error("SecretKey data is invalid");
+                    const auto &q = context.parms().coeff_modulus();
+                    for (std::size_t j = 0; j < q.size(); ++j)
+                        for (std::size_t i = 0; i < context.poly_modulus_degree(); ++i)
+                            if (data[j * context.poly_modulus_degree() + i] >= q[j])
+                                throw std::logic_error("SecretKey data is invalid");
+                    *this = SecretKey(context, data.data());
+                },
+                stream);
+        }
 
     private:
         friend class KeyGenerator;
@@ -121,6 +161,20 @@ namespace seal
         {
             return ct_;
         }
+        // publickey.h:84-190: a PublicKey is saved as its Ciphertext; a loaded one must sit at the key level
+        std::streamoff save(std::ostream &stream) const
+        {
+            return ct_.save(stream);
+        }
+        std::streamoff load(const SEALContext &context, std::istream &stream)
+        {
+            Ciphertext fresh;
+            const std::streamoff in_size = fresh.load(context, stream);
+            if (fresh.size() != 2 || fresh.coeff_modulus_size() != context.key_modulus_size() || !fresh.is_ntt_form())
+                throw std::logic_error("PublicKey data is invalid");
+            ct_ = std::move(fresh);
+            return in_size;
+        }
 
     private:
         Ciphertext ct_;
@@ -131,8 +185,10 @@ namespace seal
         // util/rlwe.cpp:282-412 without the seed-saving branch: (c0, c1) = (-(a s + e), a), BGV: -(a s + t e).
         // d_c0, d_c1: L x N device words each.  `a` comes from a second generator seeded with 64 bytes of the
         // first one (:327-334); the noise from the first one (:360).
+        // save_seed (:305-317, :347-356, :404-411): c1 is left as an indicator word followed by the serialized
+        // generator info, from which loading re-expands it; off when a polynomial is too small to hold them.
         inline void encrypt_zero_symmetric(const SecretKey &secret_key, const SEALContext &context, std::size_t L,
-                                           bool is_ntt_form, std::uint64_t *d_c0, std::uint64_t *d_c1)
+                                           bool is_ntt_form, std::uint64_t *d_c0, std::uint64_t *d_c1, bool save_seed = false)
         {
             cat_ctx *h = context.handle();
             const std::size_t n = context.poly_modulus_degree();
@@ -144,11 +200,19 @@ namespace seal
             bootstrap_prng->generate(prng_seed_byte_count, public_prng_seed.data());
             auto ciphertext_prng = UniformRandomGeneratorFactory::DefaultFactory()->create(public_prng_seed);
 
+            const std::size_t info_bytes = (std::size_t)UniformRandomGeneratorInfo::SaveSize();
+            const std::size_t info_words = (info_bytes + 7) / 8;
+            if (save_seed && L * n < info_words + 1)
+                save_seed = false;
+
             std::vector<std::uint64_t> a(L * n), noise(L * n);
-            sample_poly_uniform(ciphertext_prng, q, n, a.data()); // taken as the NTT form of a (:342-346)
+            // taken as the NTT form of a (:342-346), or as its coefficient form when a seed is kept (:347-356)
+            sample_poly_uniform(ciphertext_prng, q, n, a.data());
             sample_poly_cbd(bootstrap_prng, q, n, noise.data());
             detail::check(cat_upload(h, d_c1, a.data(), a.size() * 8, nullptr));
             detail::check(cat_stream_sync(h, nullptr));
+            if (!is_ntt_form && save_seed)
+                detail::check(cat_ntt_forward(h, d_c1, nullptr, limbs, 1, 0, nullptr));
             detail::DeviceWords d_noise(h, noise);
 
             detail::check(cat_dyadic(h, secret_key.d_data(), d_c1, d_c0, nullptr, limbs, 1, nullptr)); // :366-368
@@ -163,21 +227,34 @@ namespace seal
             }
             detail::check(cat_add(h, d_noise.get(), d_c0, d_c0, nullptr, limbs, 1, nullptr)); // :388-390
             detail::check(cat_negate(h, d_c0, d_c0, nullptr, limbs, 1, nullptr));             // :392
-            if (!is_ntt_form)
+            if (!is_ntt_form && !save_seed)
                 detail::check(cat_ntt_inverse(h, d_c1, nullptr, limbs, 1, 0, nullptr)); // :395-402
             detail::check(cat_stream_sync(h, nullptr));
+            if (save_seed)
+            {
+                // the indicator word, then the info written over the following bytes (the tail of its last word
+                // keeps what the polynomial held there, as in the reference)
+                std::vector<std::uint64_t> head(info_words + 1);
+                detail::check(cat_download(h, head.data(), d_c1, head.size() * 8, nullptr));
+                detail::check(cat_stream_sync(h, nullptr));
+                head[0] = 0xFFFFFFFFFFFFFFFFULL;
+                std::ostringstream os(std::ios::binary);
+                UniformRandomGeneratorInfo(ciphertext_prng->type(), ciphertext_prng->seed()).save(os);
+                const std::string bytes = os.str();
+                std::memcpy(head.data() + 1, bytes.data(), info_bytes);
+                detail::check(cat_upload(h, d_c1, head.data(), head.size() * 8, nullptr));
+                detail::check(cat_stream_sync(h, nullptr));
+            }
         }
 
         inline void encrypt_zero_symmetric(const SecretKey &secret_key, const SEALContext &context, std::size_t L,
                                            bool is_ntt_form, bool save_seed, Ciphertext &destination)
         {
-            if (save_seed)
-                throw std::logic_error("unsupported: seeded ciphertexts are not restated (serialization)");
             destination.resize(context, L, 2);
             destination.is_ntt_form() = is_ntt_form;
             destination.scale() = 1.0;
             destination.correction_factor() = 1;
-            encrypt_zero_symmetric(secret_key, context, L, is_ntt_form, destination.d_data(0), destination.d_data(1));
+            encrypt_zero_symmetric(secret_key, context, L, is_ntt_form, destination.d_data(0), destination.d_data(1), save_seed);
         }
 
         // util/rlwe.cpp:189-280: c[j] = pk[j] u + e[j] (BGV: + t e[j]), u ternary; one generator for u, e[0], e[1]
