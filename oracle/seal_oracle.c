@@ -2106,9 +2106,47 @@ void so_seal_gen_secret_key(const so_context *c, const uint64_t factory_seed[8],
         so_ntt_forward(sk + i * c->n, c->tables[i], 0);
 }
 
-/* util/rlwe.cpp:282-412 without save_seed: ct = 2 polys x L limbs */
+/* UniformRandomGeneratorInfo::save, compr_mode none (randomgen.cpp:99-121 inside serialization.cpp:224-265): a
+ * 16-byte SEALHeader {magic 0xA15E, header size 0x10, version 4.0, compr_mode 0, reserved, size = 81}, the prng_type
+ * byte (1 = blake2xb), the 64-byte seed */
+#define SO_PRNG_INFO_BYTES 81
+static void prng_info_save(const uint64_t seed[8], uint8_t out[SO_PRNG_INFO_BYTES])
+{
+    const uint8_t head[8] = { 0x5E, 0xA1, 0x10, 4, 0, 0, 0, 0 };
+    uint64_t size = SO_PRNG_INFO_BYTES;
+    memcpy(out, head, 8);
+    memcpy(out + 8, &size, 8);
+    out[16] = 1;
+    memcpy(out + 17, seed, 64);
+}
+
+/* util/rlwe.cpp:282-412: ct = 2 polys x L limbs; with save_seed the second polynomial ends as the indicator word
+ * 0xFFFFFFFFFFFFFFFF followed by the serialized generator info (:404-411) */
+static void seal_encrypt_zero_symmetric(const so_context *c, size_t L, const uint64_t *sk, const uint64_t factory_seed[8],
+                                        int ntt_form, int save_seed, uint64_t *ct);
+
 void so_seal_encrypt_zero_symmetric(const so_context *c, size_t L, const uint64_t *sk, const uint64_t factory_seed[8],
                                     int ntt_form, uint64_t *ct)
+{
+    seal_encrypt_zero_symmetric(c, L, sk, factory_seed, ntt_form, 0, ct);
+}
+
+void so_seal_encrypt_zero_symmetric_seeded(const so_context *c, size_t L, const uint64_t *sk,
+                                           const uint64_t factory_seed[8], int ntt_form, uint64_t *ct)
+{
+    seal_encrypt_zero_symmetric(c, L, sk, factory_seed, ntt_form, 1, ct);
+}
+
+/* Ciphertext::expand_seed (ciphertext.cpp:153-186, version 4): the second polynomial of a seeded ciphertext */
+void so_seal_expand_seed(const so_context *c, size_t L, const uint64_t seed[8], uint64_t *c1)
+{
+    so_prng *p = so_prng_create(seed);
+    so_sample_poly_uniform(p, c->primes, L, c->n, c1);
+    so_prng_destroy(p);
+}
+
+static void seal_encrypt_zero_symmetric(const so_context *c, size_t L, const uint64_t *sk, const uint64_t factory_seed[8],
+                                        int ntt_form, int save_seed, uint64_t *ct)
 {
     size_t n = c->n;
     uint64_t *c0 = ct, *c1 = ct + L * n;
@@ -2116,7 +2154,13 @@ void so_seal_encrypt_zero_symmetric(const so_context *c, size_t L, const uint64_
     uint64_t public_seed[8];
     so_prng_generate(bootstrap, 64, public_seed);
     so_prng *cprng = so_prng_create(public_seed);
+    size_t info_words = (SO_PRNG_INFO_BYTES + 7) / 8;
+    if (save_seed && L * n < info_words + 1) /* :305-317 */
+        save_seed = 0;
     so_sample_poly_uniform(cprng, c->primes, L, n, c1);
+    if (!ntt_form && save_seed) /* :347-356 */
+        for (size_t i = 0; i < L; i++)
+            so_ntt_forward(c1 + i * n, c->tables[i], 0);
     uint64_t *noise = (uint64_t *)malloc(sizeof(uint64_t) * L * n);
     so_sample_poly_cbd(bootstrap, c->primes, L, n, noise);
     for (size_t i = 0; i < L; i++)
@@ -2132,9 +2176,16 @@ void so_seal_encrypt_zero_symmetric(const so_context *c, size_t L, const uint64_
         so_add_poly_coeffmod(noise + i * n, c0 + i * n, n, m, c0 + i * n);
         so_negate_poly_coeffmod(c0 + i * n, n, m, c0 + i * n);
     }
-    if (!ntt_form)
+    if (!ntt_form && !save_seed)
         for (size_t i = 0; i < L; i++)
             so_ntt_inverse(c1 + i * n, c->tables[i], 0);
+    if (save_seed)
+    {
+        uint8_t info[SO_PRNG_INFO_BYTES];
+        prng_info_save(public_seed, info);
+        c1[0] = 0xFFFFFFFFFFFFFFFFULL;
+        memcpy(c1 + 1, info, SO_PRNG_INFO_BYTES);
+    }
     free(noise);
     so_prng_destroy(cprng);
     so_prng_destroy(bootstrap);

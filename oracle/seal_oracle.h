@@ -185,6 +185,10 @@ void so_sample_poly_uniform(so_prng *p, const uint64_t *q, size_t limbs, size_t 
 void so_seal_gen_secret_key(const so_context *c, const uint64_t factory_seed[8], uint64_t *sk /* k limbs, NTT */);
 void so_seal_encrypt_zero_symmetric(const so_context *c, size_t L, const uint64_t *sk, const uint64_t factory_seed[8],
                                     int ntt_form, uint64_t *ct /* 2 x L x N */);
+/* save_seed = true (util/rlwe.cpp:305-317, 347-356, 404-411) and Ciphertext::expand_seed (ciphertext.cpp:153-186) */
+void so_seal_encrypt_zero_symmetric_seeded(const so_context *c, size_t L, const uint64_t *sk,
+                                           const uint64_t factory_seed[8], int ntt_form, uint64_t *ct);
+void so_seal_expand_seed(const so_context *c, size_t L, const uint64_t seed[8], uint64_t *c1 /* L x N */);
 void so_seal_encrypt_zero_asymmetric(const so_context *c, size_t L, const uint64_t *pk /* 2 x k x N */,
                                      const uint64_t factory_seed[8], int ntt_form, uint64_t *ct);
 /* pk == NULL: symmetric with sk */

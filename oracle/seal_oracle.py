@@ -139,6 +139,8 @@ def lib() -> C.CDLL:
             "so_sample_poly_uniform": (None, [vp, u64p, sz, sz, u64p]),
             "so_seal_gen_secret_key": (None, [vp, u64p, u64p]),
             "so_seal_encrypt_zero_symmetric": (None, [vp, sz, u64p, u64p, C.c_int, u64p]),
+            "so_seal_encrypt_zero_symmetric_seeded": (None, [vp, sz, u64p, u64p, C.c_int, u64p]),
+            "so_seal_expand_seed": (None, [vp, sz, u64p, u64p]),
             "so_seal_encrypt_zero_asymmetric": (None, [vp, sz, u64p, u64p, C.c_int, u64p]),
             "so_seal_encrypt_zero": (None, [vp, sz, u64p, u64p, u64p, u64p]),
             "so_seal_gen_kswitch_key": (None, [vp, u64p, u64p, u64p, u64p]),
@@ -466,6 +468,17 @@ class Context:
         lib().so_seal_encrypt_zero(self.h, L, ptr(arr(pk)) if pk is not None else None,
                                    ptr(arr(sk)) if sk is not None else None, ptr(arr(seed)), ptr(ct))
         return ct
+
+    def seal_encrypt_zero_symmetric(self, L: int, sk, seed, ntt_form: bool, save_seed: bool = False) -> np.ndarray:
+        ct = np.zeros((2, L, self.n), dtype=np.uint64)
+        fn = lib().so_seal_encrypt_zero_symmetric_seeded if save_seed else lib().so_seal_encrypt_zero_symmetric
+        fn(self.h, L, ptr(arr(sk)), ptr(arr(seed)), int(ntt_form), ptr(ct))
+        return ct
+
+    def seal_expand_seed(self, L: int, seed) -> np.ndarray:
+        c1 = np.zeros((L, self.n), dtype=np.uint64)
+        lib().so_seal_expand_seed(self.h, L, ptr(arr(seed)), ptr(c1))
+        return c1
 
     def seal_relin_key(self, sk, seed) -> np.ndarray:
         key = np.zeros((self.k - 1, 2, self.k, self.n), dtype=np.uint64)
