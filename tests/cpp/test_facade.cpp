@@ -7,7 +7,9 @@
 
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <functional>
+#include <sstream>
 #include <vector>
 
 using namespace seal;
@@ -507,7 +509,186 @@ static void test_crypto(scheme_type scheme)
     so_context_destroy(oc);
 }
 
-int main()
+// the reference's wire format.  Objects made with a fixed seed are written to `dir` (the pytest
+// driver compares the files byte for byte with the oracle's restatement, oracle/seal_serialization.py), the files
+// the oracle wrote there beforehand are loaded and compared with the same objects, every object survives a round
+// trip in memory, and malformed input fails the way serialization.cpp:340-452 / ciphertext.cpp:288-400 fail.
+static void test_serialization(const std::string &dir)
+{
+    const int log_n = 12;
+    const size_t n = 4096, k = 4, L = 3;
+    const int bits[4] = { 50, 40, 40, 50 };
+    vec primes(4);
+    EXPECT(so_coeff_modulus_create(n, bits, 4, primes.data()) == 0);
+    so_context *oc = so_context_create(log_n, primes.data(), k, SO_SCHEME_CKKS, 0);
+    const prng_seed_type seed = { 201, 202, 203, 204, 205, 206, 207, 208 };
+    EncryptionParameters parms(scheme_type::ckks);
+    parms.set_poly_modulus_degree(n);
+    parms.set_coeff_modulus(primes);
+    parms.set_random_generator(std::make_shared<Blake2xbPRNGFactory>(seed));
+    SEALContext context(parms);
+    EXPECT(context.level_of(context.parms_id(2)) == 2 && context.level_of(parms_id_zero) == 0 &&
+           context.key_parms_id() != context.first_parms_id());
+
+    KeyGenerator keygen(context);
+    PublicKey public_key;
+    keygen.create_public_key(public_key);
+    RelinKeys relin_keys(context);
+    keygen.create_relin_keys(relin_keys);
+    GaloisKeys galois_keys(context);
+    keygen.create_galois_keys(std::vector<int>{ 1 }, galois_keys);
+    const uint32_t elt = so_galois_elt_from_step(log_n, 1);
+    Encryptor encryptor(context, keygen.secret_key());
+    Ciphertext ct, seeded;
+    encryptor.encrypt_zero_symmetric(L, ct);
+    ct.scale() = std::pow(2.0, 40);
+    util::encrypt_zero_symmetric(keygen.secret_key(), context, L, true, true, seeded);
+    vec seeded_words = seeded.to_cpu(), ct_words = ct.to_cpu();
+    {
+        vec e(2 * L * n);
+        so_seal_encrypt_zero_symmetric_seeded(oc, L, keygen.secret_key().to_cpu().data(), seed.data(), 1, e.data());
+        EXPECT(seeded_words == e && seeded_words[L * n] == 0xFFFFFFFFFFFFFFFFULL);
+        EXPECT(vec(seeded_words.begin(), seeded_words.begin() + L * n) == vec(ct_words.begin(), ct_words.begin() + L * n));
+    }
+    vec pl = uniform(oc, L, 1, n, 55);
+    Plaintext plain(context, L);
+    plain.upload(pl.data());
+    plain.scale() = std::pow(2.0, 40);
+
+    auto write = [&](const char *name, const std::function<void(std::ostream &)> &save) {
+        std::ofstream f(dir + "/" + name, std::ios::binary);
+        save(f);
+        EXPECT(f.good());
+    };
+    write("facade_sk.bin", [&](std::ostream &s) { keygen.secret_key().save(context, s); });
+    write("facade_pk.bin", [&](std::ostream &s) { public_key.save(s); });
+    write("facade_rk.bin", [&](std::ostream &s) { relin_keys.save(s); });
+    write("facade_gk.bin", [&](std::ostream &s) { galois_keys.save(s); });
+    write("facade_ct.bin", [&](std::ostream &s) { EXPECT(ct.save(s) == ct.save_size()); });
+    write("facade_seeded.bin", [&](std::ostream &s) { EXPECT(seeded.save(s) == seeded.save_size(true)); });
+    write("facade_plain.bin", [&](std::ostream &s) { plain.save(s); });
+
+    // round trips in memory
+    {
+        std::stringstream s(std::ios::in | std::ios::out | std::ios::binary);
+        ct.save(s);
+        seeded.save(s);
+        plain.save(s);
+        keygen.secret_key().save(context, s);
+        public_key.save(s);
+        relin_keys.save(s);
+        galois_keys.save(s);
+        Ciphertext a, b;
+        EXPECT(a.load(context, s) == ct.save_size());
+        EXPECT(a.to_cpu() == ct_words && a.is_ntt_form() && a.scale() == ct.scale() && a.coeff_modulus_size() == L);
+        b.load(context, s);
+        EXPECT(b.to_cpu() == ct_words); // the expanded seed gives back the second polynomial
+        Plaintext p2(context, 1);
+        p2.load(context, s);
+        EXPECT(p2.to_cpu() == pl && p2.scale() == plain.scale() && p2.coeff_modulus_size() == L);
+        SecretKey sk2;
+        sk2.load(context, s);
+        EXPECT(sk2.to_cpu() == keygen.secret_key().to_cpu());
+        PublicKey pk2;
+        pk2.load(context, s);
+        EXPECT(pk2.data().to_cpu() == public_key.data().to_cpu());
+        RelinKeys rk2(context);
+        rk2.load(context, s);
+        EXPECT(rk2.has_key(2) && rk2.size() == 1 && rk2.key_to_cpu(0) == relin_keys.key_to_cpu(0));
+        GaloisKeys gk2(context);
+        gk2.load(context, s);
+        EXPECT(gk2.has_key(elt) && gk2.size() == 1 &&
+               gk2.key_to_cpu(GaloisKeys::get_index(elt)) == galois_keys.key_to_cpu(GaloisKeys::get_index(elt)));
+        // loaded keys work: relinearize with rk2 equals relinearize with the original
+        vec x = uniform(oc, L, 3, n, 56);
+        Ciphertext c3(context, L, 3), c3b(context, L, 3);
+        c3.upload(x.data());
+        c3b.upload(x.data());
+        c3.is_ntt_form() = c3b.is_ntt_form() = true;
+        Evaluator evaluator(context);
+        evaluator.relinearize_inplace(c3, relin_keys);
+        evaluator.relinearize_inplace(c3b, rk2);
+        EXPECT(c3.to_cpu() == c3b.to_cpu());
+    }
+
+    // files written by the oracle with the same parameters and seed
+    auto open = [&](const char *name) { return std::ifstream(dir + "/" + name, std::ios::binary); };
+    if (open("oracle_ct.bin").good())
+    {
+        std::ifstream f = open("oracle_ct.bin");
+        Ciphertext a;
+        a.load(context, f);
+        EXPECT(a.to_cpu() == ct_words && a.scale() == ct.scale());
+        f = open("oracle_seeded.bin");
+        a.load(context, f);
+        EXPECT(a.to_cpu() == ct_words);
+        f = open("oracle_sk.bin");
+        SecretKey sk2;
+        sk2.load(context, f);
+        EXPECT(sk2.to_cpu() == keygen.secret_key().to_cpu());
+        f = open("oracle_pk.bin");
+        PublicKey pk2;
+        pk2.load(context, f);
+        EXPECT(pk2.data().to_cpu() == public_key.data().to_cpu());
+        f = open("oracle_rk.bin");
+        RelinKeys rk2(context);
+        rk2.load(context, f);
+        EXPECT(rk2.key_to_cpu(0) == relin_keys.key_to_cpu(0));
+        f = open("oracle_gk.bin");
+        GaloisKeys gk2(context);
+        gk2.load(context, f);
+        EXPECT(gk2.key_to_cpu(GaloisKeys::get_index(elt)) == galois_keys.key_to_cpu(GaloisKeys::get_index(elt)));
+        f = open("oracle_plain.bin");
+        Plaintext p2(context, 1);
+        p2.load(context, f);
+        EXPECT(p2.to_cpu() == pl);
+        std::printf("serialization: oracle files loaded\n");
+    }
+
+    // malformed input
+    {
+        std::ostringstream os(std::ios::binary);
+        ct.save(os);
+        const std::string good = os.str();
+        auto load_from = [&](std::string bytes) {
+            std::istringstream is(bytes, std::ios::binary);
+            Ciphertext a;
+            a.load(context, is);
+        };
+        std::string bad = good;
+        bad[0] = 0;
+        EXPECT(throws<std::logic_error>([&] { load_from(bad); })); // "loaded SEALHeader is invalid"
+        bad = good;
+        bad[5] = 1;
+        EXPECT(throws<std::invalid_argument>([&] { load_from(bad); })); // "unsupported compression mode"
+        bad = good;
+        bad[3] = 5;
+        EXPECT(throws<std::logic_error>([&] { load_from(bad); })); // "incompatible version"
+        bad = good;
+        bad[16] ^= 1;
+        EXPECT(throws<std::logic_error>([&] { load_from(bad); })); // unknown parms_id: "ciphertext data is invalid"
+        bad = good;
+        bad[16 + 32 + 1 + 16] = 2; // limb count of another level
+        EXPECT(throws<std::logic_error>([&] { load_from(bad); }));
+        bad = good;
+        bad[8] ^= 1; // header size field no longer matches what was read
+        EXPECT(throws<std::logic_error>([&] { load_from(bad); })); // "invalid data size"
+        EXPECT(throws<std::runtime_error>([&] { load_from(good.substr(0, good.size() - 9)); })); // "I/O error"
+        // another context's parameters: the parms_id is unknown there
+        EncryptionParameters other(scheme_type::ckks);
+        other.set_poly_modulus_degree(n);
+        other.set_coeff_modulus(vec(primes.begin(), primes.begin() + 3));
+        SEALContext context2(other);
+        EXPECT(throws<std::logic_error>([&] {
+            std::istringstream is(good, std::ios::binary);
+            Ciphertext a;
+            a.load(context2, is);
+        }));
+    }
+    so_context_destroy(oc);
+}
+
+int main(int argc, char **argv)
 {
     try
     {
@@ -518,6 +699,8 @@ int main()
         test_crypto(scheme_type::ckks);
         test_crypto(scheme_type::bfv);
         test_crypto(scheme_type::bgv);
+        if (argc > 1)
+            test_serialization(argv[1]);
     }
     catch (const std::exception &e)
     {
