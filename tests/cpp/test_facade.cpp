@@ -674,10 +674,20 @@ static void test_serialization(const std::string &dir)
         bad[8] ^= 1; // header size field no longer matches what was read
         EXPECT(throws<std::logic_error>([&] { load_from(bad); })); // "invalid data size"
         EXPECT(throws<std::runtime_error>([&] { load_from(good.substr(0, good.size() - 9)); })); // "I/O error"
-        // another context's parameters: the parms_id is unknown there
-        EncryptionParameters other(scheme_type::ckks);
+        // a context over the same three primes has this level as its key level and accepts the object (pure key levels
+        // are allowed, ciphertext.cpp:331-342); with the primes in another order the parms_id is unknown
+        EncryptionParameters same(scheme_type::ckks), other(scheme_type::ckks);
+        same.set_poly_modulus_degree(n);
+        same.set_coeff_modulus(vec(primes.begin(), primes.begin() + 3));
+        SEALContext context3(same);
+        {
+            std::istringstream is(good, std::ios::binary);
+            Ciphertext a;
+            a.load(context3, is);
+            EXPECT(a.to_cpu() == ct_words);
+        }
         other.set_poly_modulus_degree(n);
-        other.set_coeff_modulus(vec(primes.begin(), primes.begin() + 3));
+        other.set_coeff_modulus({ primes[1], primes[0], primes[2] });
         SEALContext context2(other);
         EXPECT(throws<std::logic_error>([&] {
             std::istringstream is(good, std::ios::binary);
