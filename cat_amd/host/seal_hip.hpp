@@ -424,7 +424,7 @@ namespace seal
                         correction_factor = util::read_pod<std::uint64_t>(s);
                     // is_metadata_valid_for(..., allow_pure_key_levels = true), valcheck.cpp
                     const std::size_t L = context.level_of(id);
-                    if (!L || n64 != context.poly_modulus_degree() || L64 != L || size64 < 2 || size64 > 6)
+                    if (!L || n64 != context.poly_modulus_degree() || L64 != L || size64 < 2 || size64 > 16) // SEAL_CIPHERTEXT_SIZE_MIN .. _MAX, util/defines.h:66-70
                         throw std::logic_error("ciphertext data is invalid");
                     const std::size_t total = (std::size_t)size64 * L * (std::size_t)n64;
                     std::vector<std::uint64_t> data = util::dynarray_load(s, total);
