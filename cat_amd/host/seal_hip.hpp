@@ -895,9 +895,14 @@ namespace seal
             verify(encrypted2, "encrypted2");
             if (encrypted1.coeff_modulus_size() != encrypted2.coeff_modulus_size())
                 throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
-            if (encrypted1.size() != 2 || encrypted2.size() != 2)
-                throw std::logic_error("unsupported: only size-2 operands are multiplied on the device");
             const std::uint32_t L = (std::uint32_t)encrypted1.coeff_modulus_size();
+            if (encrypted1.size() != 2 || encrypted2.size() != 2)
+            {
+                if (context_.parms().scheme() == scheme_type::bfv)
+                    throw std::logic_error("unsupported: BFV operands larger than size 2 are not multiplied on the device");
+                multiply_general(encrypted1, encrypted2);
+                return;
+            }
             Ciphertext dest(context_, L, 3);
             switch (context_.parms().scheme())
             {
@@ -1150,6 +1155,41 @@ namespace seal
         std::uint64_t mul_mod_t(std::uint64_t a, std::uint64_t b) const
         {
             return (std::uint64_t)((unsigned __int128)a * b % context_.parms().plain_modulus());
+        }
+        // ckks_multiply / bgv_multiply for other sizes (evaluator.cpp:664-700, 800-836): output polynomial I is the sum
+        // of the dyadic products x[a] y[I - a]
+        void multiply_general(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
+        {
+            if (!encrypted1.is_ntt_form() || !encrypted2.is_ntt_form())
+                throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
+            const std::size_t xs = encrypted1.size(), ys = encrypted2.size(), dest_size = xs + ys - 1;
+            if (dest_size > 16) // SEAL_CIPHERTEXT_SIZE_MAX
+                throw std::logic_error("invalid parameters");
+            const std::uint32_t L = (std::uint32_t)encrypted1.coeff_modulus_size();
+            const std::size_t poly = (std::size_t)L * context_.poly_modulus_degree();
+            Ciphertext dest(context_, L, dest_size), prod(context_, L, 2);
+            for (std::size_t I = 0; I < dest_size; ++I)
+            {
+                const std::size_t last1 = std::min(I, xs - 1), first2 = std::min(I, ys - 1), first1 = I - first2;
+                for (std::size_t a = first1; a <= last1; ++a)
+                {
+                    std::uint64_t *out = a == first1 ? dest.d_data(I) : prod.d_data();
+                    detail::check(cat_dyadic(h(), encrypted1.d_data() + a * poly, encrypted2.d_data() + (I - a) * poly, out,
+                                             nullptr, L, 1, nullptr));
+                    if (a != first1)
+                        detail::check(cat_add(h(), dest.d_data(I), prod.d_data(), dest.d_data(I), nullptr, L, 1, nullptr));
+                }
+            }
+            detail::check(cat_stream_sync(h(), nullptr));
+            dest.is_ntt_form() = true;
+            if (context_.parms().scheme() == scheme_type::bgv)
+            {
+                dest.scale() = encrypted1.scale();
+                dest.correction_factor() = mul_mod_t(encrypted1.correction_factor(), encrypted2.correction_factor());
+            }
+            else
+                dest.scale() = encrypted1.scale() * encrypted2.scale();
+            encrypted1 = std::move(dest);
         }
         void plain_addsub(Ciphertext &encrypted, const Plaintext &plain, bool sub) const
         {

@@ -201,6 +201,20 @@ static void test_ckks()
         EXPECT(throws<std::invalid_argument>([&] { evaluator.apply_galois_inplace(r, 4, galois_keys); }));
     }
 
+    // multiply of larger operands (evaluator.cpp:664-700): 3 x 2 -> 4, then relinearize 4 -> 2 needs the s^3 key
+    {
+        vec x3 = uniform(oc, L, 3, n, 13), e(4 * L * n, 0);
+        Ciphertext a(context, L, 3);
+        a.upload(x3.data());
+        a.is_ntt_form() = true;
+        a.scale() = delta;
+        std::memcpy(e.data(), x3.data(), x3.size() * 8);
+        so_ckks_multiply_general(oc, L, e.data(), 3, y.data(), 2);
+        evaluator.multiply_inplace(a, encrypted2);
+        EXPECT(a.size() == 4 && a.to_cpu() == e && a.scale() == delta * delta);
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.relinearize_inplace(a, relin_keys); })); // "not enough relinearization keys"
+    }
+
     // mod_switch_to_next (drop) and the NTT transforms
     {
         Ciphertext m(encrypted2);
