@@ -20,7 +20,9 @@
 #include "../../include/cat_amd.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <memory>
 #include <new>
@@ -867,25 +869,15 @@ namespace seal
                                      nullptr));
         }
 
-        // evaluator.cpp:133-215 for equal sizes (the larger-operand copy branch is host bookkeeping)
+        // evaluator.cpp:145-237 and :265-350: operands of different sizes (the longer tail is copied, or negated for a
+        // subtraction) and, in BGV, of different correction factors (both sides are scaled first, :196-216)
         void add_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
         {
-            check_pair(encrypted1, encrypted2);
-            if (encrypted1.size() != encrypted2.size())
-                throw std::logic_error("unsupported: operands of different size");
-            detail::check(cat_add(h(), encrypted1.d_data(), encrypted2.d_data(), encrypted1.d_data(), nullptr,
-                                  (std::uint32_t)encrypted1.coeff_modulus_size(), (std::uint32_t)encrypted1.size(),
-                                  nullptr));
+            add_sub(encrypted1, encrypted2, false);
         }
-
         void sub_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
         {
-            check_pair(encrypted1, encrypted2);
-            if (encrypted1.size() != encrypted2.size())
-                throw std::logic_error("unsupported: operands of different size");
-            detail::check(cat_sub(h(), encrypted1.d_data(), encrypted2.d_data(), encrypted1.d_data(), nullptr,
-                                  (std::uint32_t)encrypted1.coeff_modulus_size(), (std::uint32_t)encrypted1.size(),
-                                  nullptr));
+            add_sub(encrypted1, encrypted2, true);
         }
 
         // evaluator.cpp:352-393 -> ckks_multiply :569-708 / bfv_multiply :395-567 (sizes 2 x 2 -> 3)
@@ -1147,10 +1139,103 @@ namespace seal
                 throw std::invalid_argument("NTT form mismatch");
             if (a.scale() != b.scale())
                 throw std::invalid_argument("scale mismatch");
-            // evaluator.cpp:168-199 balances BGV operands whose correction factors differ; host bookkeeping plus two
-            // scalar multiplications that this facade does not restate
-            if (a.correction_factor() != b.correction_factor())
-                throw std::logic_error("unsupported: operands with different correction factors");
+        }
+        // balance_correction_factors (evaluator.cpp:56-118): {new factor, e1, e2} with e1 f1 = e2 f2 (mod t) and
+        // |e1| + |e2| smallest among the remainders of the extended Euclidean run on (t, f2 / f1)
+        std::array<std::uint64_t, 3> balance_correction_factors(std::uint64_t factor1, std::uint64_t factor2) const
+        {
+            using u128 = unsigned __int128;
+            const std::uint64_t t = context_.parms().plain_modulus(), half_t = t / 2;
+            auto bal = [&](std::uint64_t x) { return (std::int64_t)(x > half_t ? x - t : x); };
+            auto sum_abs = [&](std::uint64_t x, std::uint64_t y) { return std::llabs(bal(x)) + std::llabs(bal(y)); };
+            auto gcd = [](std::uint64_t a, std::uint64_t b) {
+                while (b)
+                {
+                    const std::uint64_t r = a % b;
+                    a = b;
+                    b = r;
+                }
+                return a;
+            };
+            // f1^-1 mod t by the extended Euclidean algorithm
+            std::uint64_t ratio = 0;
+            {
+                __int128 r0 = t, r1 = factor1 % t, t0 = 0, t1 = 1;
+                while (r1)
+                {
+                    const __int128 q = r0 / r1, r2 = r0 - q * r1, t2 = t0 - q * t1;
+                    r0 = r1, r1 = r2, t0 = t1, t1 = t2;
+                }
+                if (r0 != 1)
+                    throw std::logic_error("invalid correction factor1");
+                ratio = (std::uint64_t)(t0 < 0 ? t0 + t : t0);
+            }
+            ratio = (std::uint64_t)((u128)ratio * factor2 % t);
+            std::uint64_t e1 = ratio, e2 = 1;
+            std::int64_t sum = sum_abs(e1, e2);
+            std::int64_t prev_a = (std::int64_t)t, prev_b = 0, a = (std::int64_t)ratio, b = 1;
+            while (a != 0)
+            {
+                const std::int64_t q = prev_a / a;
+                std::int64_t temp = prev_a % a;
+                prev_a = a;
+                a = temp;
+                temp = prev_b - b * q;
+                prev_b = b;
+                b = temp;
+                std::uint64_t a_mod = (std::uint64_t)std::llabs(a) % t;
+                if (a < 0 && a_mod)
+                    a_mod = t - a_mod;
+                std::uint64_t b_mod = (std::uint64_t)std::llabs(b) % t;
+                if (b < 0 && b_mod)
+                    b_mod = t - b_mod;
+                if (a_mod != 0 && gcd(a_mod, t) == 1)
+                {
+                    const std::int64_t new_sum = sum_abs(a_mod, b_mod);
+                    if (new_sum < sum)
+                    {
+                        sum = new_sum;
+                        e1 = a_mod;
+                        e2 = b_mod;
+                    }
+                }
+            }
+            return { (std::uint64_t)((u128)e1 * factor1 % t), e1, e2 };
+        }
+        void add_sub(Ciphertext &encrypted1, const Ciphertext &encrypted2, bool sub) const
+        {
+            check_pair(encrypted1, encrypted2);
+            const std::uint32_t L = (std::uint32_t)encrypted1.coeff_modulus_size();
+            if (encrypted1.correction_factor() != encrypted2.correction_factor())
+            {
+                const auto factors = balance_correction_factors(encrypted1.correction_factor(), encrypted2.correction_factor());
+                const std::vector<std::uint64_t> f1(L, factors[1]), f2(L, factors[2]);
+                detail::check(cat_mul_scalar(h(), encrypted1.d_data(), f1.data(), encrypted1.d_data(), nullptr, L,
+                                             (std::uint32_t)encrypted1.size(), nullptr));
+                Ciphertext encrypted2_copy(encrypted2);
+                detail::check(cat_mul_scalar(h(), encrypted2_copy.d_data(), f2.data(), encrypted2_copy.d_data(), nullptr, L,
+                                             (std::uint32_t)encrypted2_copy.size(), nullptr));
+                encrypted1.correction_factor() = factors[0];
+                encrypted2_copy.correction_factor() = factors[0];
+                add_sub(encrypted1, encrypted2_copy, sub);
+                return;
+            }
+            const std::size_t size1 = encrypted1.size(), size2 = encrypted2.size(), min_count = std::min(size1, size2);
+            if (size1 < size2)
+                encrypted1.resize(size2); // keeps the polynomials it has (ciphertext.cpp:76-107)
+            auto fn = sub ? cat_sub : cat_add;
+            detail::check(fn(h(), encrypted1.d_data(), encrypted2.d_data(), encrypted1.d_data(), nullptr, L,
+                             (std::uint32_t)min_count, nullptr));
+            if (size1 < size2)
+            {
+                // the rest of encrypted2: copied (reducing a reduced value copies it) or negated
+                const std::uint64_t *src = encrypted2.d_data() + min_count * L * context_.poly_modulus_degree();
+                if (sub)
+                    detail::check(cat_negate(h(), src, encrypted1.d_data(size1), nullptr, L, (std::uint32_t)(size2 - size1), nullptr));
+                else
+                    detail::check(cat_modulo(h(), src, encrypted1.d_data(size1), nullptr, L, (std::uint32_t)(size2 - size1), nullptr));
+            }
+            detail::check(cat_stream_sync(h(), nullptr));
         }
         std::uint64_t mul_mod_t(std::uint64_t a, std::uint64_t b) const
         {

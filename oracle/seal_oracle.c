@@ -2321,3 +2321,62 @@ void so_seal_dot_product_ct_sk(const so_context *c, size_t L, const uint64_t *sk
     free(sp);
     free(acc);
 }
+
+/* evaluator.cpp:56-118 balance_correction_factors: out = {new factor, e1, e2} with e1 f1 = e2 f2 (mod t) and
+ * |e1| + |e2| smallest among the remainders of the extended Euclidean run on (t, f2 / f1) */
+static uint64_t gcd_u64(uint64_t a, uint64_t b)
+{
+    while (b)
+    {
+        uint64_t r = a % b;
+        a = b;
+        b = r;
+    }
+    return a;
+}
+
+int so_balance_correction_factors(uint64_t factor1, uint64_t factor2, uint64_t t, uint64_t out[3])
+{
+    so_modulus pm;
+    so_modulus_init(&pm, t);
+    uint64_t half_t = t / 2, ratio = 1;
+    if (!so_try_invert_uint_mod(factor1, t, &ratio))
+        return -1;
+    ratio = so_multiply_uint_mod(ratio, factor2, &pm);
+#define SO_BAL(x) ((int64_t)((x) > half_t ? (x)-t : (x)))
+#define SO_SUM_ABS(x, y) (llabs(SO_BAL(x)) + llabs(SO_BAL(y)))
+    uint64_t e1 = ratio, e2 = 1;
+    int64_t sum = SO_SUM_ABS(e1, e2);
+    int64_t prev_a = (int64_t)t, prev_b = 0, a = (int64_t)ratio, b = 1;
+    while (a != 0)
+    {
+        int64_t q = prev_a / a, temp = prev_a % a;
+        prev_a = a;
+        a = temp;
+        temp = prev_b - b * q;
+        prev_b = b;
+        b = temp;
+        uint64_t a_mod = so_barrett_reduce_64((uint64_t)llabs(a), &pm);
+        if (a < 0)
+            a_mod = so_negate_uint_mod(a_mod, &pm);
+        uint64_t b_mod = so_barrett_reduce_64((uint64_t)llabs(b), &pm);
+        if (b < 0)
+            b_mod = so_negate_uint_mod(b_mod, &pm);
+        if (a_mod != 0 && gcd_u64(a_mod, t) == 1)
+        {
+            int64_t new_sum = SO_SUM_ABS(a_mod, b_mod);
+            if (new_sum < sum)
+            {
+                sum = new_sum;
+                e1 = a_mod;
+                e2 = b_mod;
+            }
+        }
+    }
+#undef SO_BAL
+#undef SO_SUM_ABS
+    out[0] = so_multiply_uint_mod(e1, factor1, &pm);
+    out[1] = e1;
+    out[2] = e2;
+    return 0;
+}

@@ -202,6 +202,10 @@ void so_seal_gen_galois_key(const so_context *c, const uint64_t *sk, uint32_t el
 void so_seal_dot_product_ct_sk(const so_context *c, size_t L, const uint64_t *sk, const uint64_t *ct, size_t size,
                                int ntt_form, uint64_t *out /* L limbs */);
 
+/* evaluator.cpp:56-118: BGV operands with different correction factors; out = {new factor, scalar for the first,
+ * scalar for the second}; -1 when factor1 is not invertible */
+int so_balance_correction_factors(uint64_t factor1, uint64_t factor2, uint64_t t, uint64_t out[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -343,6 +343,40 @@ static void test_bgv()
     EXPECT(encrypted1.correction_factor() == 15 * inv % t);
     EXPECT(throws<std::invalid_argument>([&] { evaluator.rescale_to_next_inplace(encrypted2); }));
 
+    // add / sub of operands with different correction factors and sizes (evaluator.cpp:196-237, 302-350)
+    for (int sub = 0; sub < 2; ++sub)
+    {
+        vec a3 = uniform(oc, L, 2, n, 32), b3 = uniform(oc, L, 3, n, 33);
+        Ciphertext a(context, L, 2), b(context, L, 3);
+        a.upload(a3.data());
+        b.upload(b3.data());
+        a.is_ntt_form() = b.is_ntt_form() = true;
+        a.correction_factor() = 7;
+        b.correction_factor() = 12345;
+        uint64_t f[3];
+        EXPECT(so_balance_correction_factors(7, 12345, t, f) == 0);
+        EXPECT((unsigned __int128)f[1] * 7 % t == (unsigned __int128)f[2] * 12345 % t && f[0] == f[1] * 7 % t);
+        vec e(3 * L * n);
+        for (size_t p = 0; p < 3; ++p)
+            for (size_t j = 0; j < L; ++j)
+            {
+                const so_modulus *m = &so_context_tables(oc, j)->mod;
+                vec sb(n), sa(n, 0);
+                so_multiply_poly_scalar_coeffmod(&b3[(p * L + j) * n], n, f[2], m, sb.data());
+                if (p < 2)
+                    so_multiply_poly_scalar_coeffmod(&a3[(p * L + j) * n], n, f[1], m, sa.data());
+                if (sub)
+                    so_sub_poly_coeffmod(sa.data(), sb.data(), n, m, &e[(p * L + j) * n]);
+                else
+                    so_add_poly_coeffmod(sa.data(), sb.data(), n, m, &e[(p * L + j) * n]);
+            }
+        if (sub)
+            evaluator.sub_inplace(a, b);
+        else
+            evaluator.add_inplace(a, b);
+        EXPECT(a.size() == 3 && a.correction_factor() == f[0] && a.to_cpu() == e);
+    }
+
     vec r = y;
     so_apply_galois_inplace(oc, L, r.data(), elt, gk.data());
     evaluator.rotate_rows_inplace(encrypted2, 1, galois_keys);
