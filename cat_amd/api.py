@@ -244,6 +244,13 @@ class Context:
         _check(self.lib.cat_relinearize(self.h, self._p(ct3), self._p(key), L, b, self._stream()))
         return ct3[:, :2]
 
+    def relinearize_rescale(self, ct3, key, out=None):
+        """ct3: [batch, 3, L, N] (scratch afterwards) -> [batch, 2, L-1, N] = rescale(relinearize(ct3))"""
+        b, _, L, _ = ct3.shape
+        out = torch.empty((b, 2, L - 1, self.n), dtype=torch.int64, device=ct3.device) if out is None else out
+        _check(self.lib.cat_relinearize_rescale(self.h, self._p(ct3), self._p(key), self._p(out), L, b, self._stream()))
+        return out
+
     def rescale(self, ct, out=None):
         b, size, L, _ = ct.shape
         out = torch.empty((b, size, L - 1, self.n), dtype=torch.int64, device=ct.device) if out is None else out

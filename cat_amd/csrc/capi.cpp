@@ -638,6 +638,39 @@ cat_status cat_relinearize(cat_ctx *ctx, uint64_t *ct3, const uint64_t *key, uin
                              stride, stride, (hipStream_t)s);
 }
 
+cat_status cat_relinearize_rescale(cat_ctx *ctx, uint64_t *ct3, const uint64_t *key, uint64_t *out, uint32_t L,
+                                   uint32_t batch, cat_stream s)
+{
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if (!key)
+        return fail(CAT_ERR_INVALID_ARG, "relin_keys is not valid for encryption parameters");
+    if (!ct3 || !out)
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (ctx->scheme == CAT_SCHEME_NONE || ctx->k < 2)
+        return fail(CAT_ERR_LOGIC, "keyswitching is not supported by the context");
+    if (L == 0 || L >= ctx->k || L >= 256)
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (L < 2)
+        return fail(CAT_ERR_INVALID_ARG, "end of modulus switching chain reached");
+    if (batch == 0)
+        return CAT_OK;
+    const size_t N = ctx->n, stride = (size_t)3 * L * N, out_stride = (size_t)2 * (L - 1) * N;
+    const u64 *in_end = (const u64 *)ct3 + (size_t)batch * stride, *out_end = (const u64 *)out + (size_t)batch * out_stride;
+    if (!(out_end <= (const u64 *)ct3 || in_end <= (const u64 *)out))
+        return fail(CAT_ERR_INVALID_ARG, "destination must not alias the inputs");
+    if (ctx->scheme == CAT_SCHEME_CKKS && ctx->log_n >= 12)
+        return launch_switch_key(ctx, (u64 *)ct3, (const u64 *)ct3 + (size_t)2 * L * N, (const u64 *)key, L, batch, stride,
+                                 stride, (hipStream_t)s, (u64 *)out, out_stride);
+    // other schemes and small degrees: the two steps one after the other
+    st = launch_switch_key(ctx, (u64 *)ct3, (const u64 *)ct3 + (size_t)2 * L * N, (const u64 *)key, L, batch, stride, stride,
+                           (hipStream_t)s);
+    if (st != CAT_OK)
+        return st;
+    return launch_rescale(ctx, (const u64 *)ct3, (u64 *)out, L, 2, batch, stride, out_stride, (hipStream_t)s);
+}
+
 cat_status cat_rescale(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t L, uint32_t size, uint32_t batch,
                        cat_stream s)
 {

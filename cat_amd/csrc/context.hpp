@@ -120,6 +120,17 @@ namespace cat
         int ep_acc = 0;
         uint32_t ep_qidx = 0;
         bool first_pass_only = false; // forward, N >= 4096: run the column pass alone (the caller finishes the rows)
+        // Dual form (relinearize followed by rescale as ONE transform per limb, keyswitch.hip): the input is
+        //   round(src; Q) * Q^-1 + round(src2; Q2)      (Q = prime src_qidx, Q2 = prime src2_qidx)
+        // and the epilogue dest = ((other + other2 * Q2e^-1) + 4q - t) * Qe^-1 with Qe = prime ep_qidx,
+        // Q2e = prime ep_qidx2.  By linearity of the transform this equals the mod-down finish followed by the
+        // rescale finish modulo q, and the output is canonical.
+        const u64 *src2 = nullptr;
+        u64 src2_stride = 0;
+        uint32_t src2_qidx = 0;
+        const u64 *ep_other2 = nullptr;
+        u64 ep_other2_b = 0, ep_other2_s = 0;
+        uint32_t ep_qidx2 = 0;
     };
     // general form: objects `poly_stride` words apart; limb j uses modulus map.id[j / limb_group];
     // skip_diag skips limbs with j % limb_group == j / limb_group (key switching's I == J operands)
@@ -142,8 +153,11 @@ namespace cat
     // out[b][0] = in[b][0], out[b][1] = 0 for `batch` size-2 ciphertexts of L limbs
     cat_status launch_copy_c0_zero_c1(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t batch, hipStream_t s);
     // enc_stride / target_stride: words between consecutive ciphertexts / targets of the batch
+    // rescale_out != nullptr (CKKS, N >= 4096, L >= 2): the mod-down is followed by rescale_to_next of the size-2
+    // result, written to rescale_out ([batch][2][L-1][N], out_stride words apart); enc keeps only its last limb updated
     cat_status launch_switch_key(cat_ctx *ctx, u64 *enc, const u64 *target, const u64 *key, uint32_t L, uint32_t batch,
-                                 size_t enc_stride, size_t target_stride, hipStream_t s);
+                                 size_t enc_stride, size_t target_stride, hipStream_t s, u64 *rescale_out = nullptr,
+                                 size_t out_stride = 0);
     cat_status launch_rescale(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t size, uint32_t batch,
                               size_t in_stride, size_t out_stride, hipStream_t s);
     enum { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_DYADIC = 3, EW_MODULO = 4, SCALAR_MUL = 0, SCALAR_ADD = 1, SCALAR_SUB = 2 };

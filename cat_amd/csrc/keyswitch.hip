@@ -546,7 +546,7 @@ namespace
 namespace cat
 {
     cat_status launch_switch_key(cat_ctx *ctx, u64 *enc, const u64 *target, const u64 *key, uint32_t L, uint32_t batch,
-                                 size_t enc_stride, size_t target_stride, hipStream_t s)
+                                 size_t enc_stride, size_t target_stride, hipStream_t s, u64 *rescale_out, size_t out_stride)
     {
         const u32 d = L, k = ctx->k, rns = d + 1, log_n = ctx->log_n;
         const size_t N = ctx->n;
@@ -556,10 +556,13 @@ namespace cat
         const size_t w_ext = (size_t)batch * rns * d * N;
         const size_t w_prod = (size_t)batch * 2 * rns * N;
         const size_t w_tmp = (size_t)batch * 2 * d * N;
-        u64 *ws = (u64 *)workspace(ctx, (w_target + w_ext + w_prod + w_tmp) * sizeof(u64));
+        const size_t w_last = rescale_out ? (size_t)batch * 2 * N : 0;
+        u64 *ws = (u64 *)workspace(ctx, (w_target + w_ext + w_prod + w_tmp + w_last) * sizeof(u64));
         if (!ws)
             return CAT_ERR_NOMEM;
-        u64 *t_target = ws, *ext = t_target + w_target, *prod = ext + w_ext, *tmp = prod + w_prod;
+        u64 *t_target = ws, *ext = t_target + w_target, *prod = ext + w_ext, *tmp = prod + w_prod, *last = tmp + w_tmp;
+        if (rescale_out && (ctx->scheme != CAT_SCHEME_CKKS || log_n < 12 || d < 2))
+            return fail(CAT_ERR_LOGIC, "unsupported fused transform");
         const LimbMap ident = ctx->identity_map();
 
         // step 1
@@ -701,6 +704,69 @@ namespace cat
                 hipLaunchKernelGGL(ks_down_finish_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
                 CAT_HIP(hipGetLastError());
                 return CAT_OK;
+            }
+            if (rescale_out)
+            {
+                // relinearize + rescale_to_next with ONE forward transform per remaining limb.  Sequentially
+                //   enc'[j] = enc[j] + (prod[j] - NTT(r1_j)) P^-1,   out[j] = (enc'[j] - NTT(r2_j)) q_last^-1,
+                // r1 = the mod-down round source (from INTT_P of the special limb), r2 = the rescale round source
+                // (from INTT of enc'[d-1], util/rns.cpp:857-878); the transform is linear, so
+                //   out[j] = (enc[j] + prod[j] P^-1 - NTT(r1_j P^-1 + r2_j)) q_last^-1   (mod q_j, canonical).
+                // (a) the last limb alone, as in the unfused mod-down: enc'[d-1]
+                NttFuse f;
+                f.src = prod + (size_t)d * N;
+                f.src_stride = (u64)rns * N;
+                f.src_kind = 1;
+                f.src_qidx = k - 1;
+                f.ep_other = prod + (size_t)(d - 1) * N;
+                f.ep_other_b = (u64)2 * rns * N;
+                f.ep_other_s = (u64)rns * N;
+                f.ep_dest = enc + (size_t)(d - 1) * N;
+                f.ep_dest_b = enc_stride;
+                f.ep_dest_s = (u64)d * N;
+                f.ep_S = 2;
+                f.ep_acc = 1;
+                f.ep_qidx = k - 1;
+                LimbMap ml{};
+                ml.id[0] = (unsigned char)(d - 1);
+                st = launch_ntt_ex(ctx, true, tmp, ml, 1, batch * 2, true, (u64)N, 1, false, s, false, &f);
+                if (st != CAT_OK)
+                    return st;
+                // (b) its canonical inverse transform, gathered per polynomial (rns.cpp:845-855)
+                RescaleArgs r{};
+                r.in = enc;
+                r.L = d;
+                r.log_n = log_n;
+                r.size = 2;
+                r.in_stride2 = enc_stride / 2;
+                hipLaunchKernelGGL(gather_last_kernel, dim3(grid_for(w_last / 2)), dim3(256), 0, s, r, last, (u64)w_last / 2);
+                CAT_HIP(hipGetLastError());
+                st = launch_ntt(ctx, false, last, ml, 1, batch * 2, false, s);
+                if (st != CAT_OK)
+                    return st;
+                // (c) the remaining d-1 limbs: dual source, two-term epilogue
+                NttFuse g2;
+                g2.src = prod + (size_t)d * N;
+                g2.src_stride = (u64)rns * N;
+                g2.src_kind = 1;
+                g2.src_qidx = k - 1;
+                g2.src2 = last;
+                g2.src2_stride = N;
+                g2.src2_qidx = d - 1;
+                g2.ep_other = enc;
+                g2.ep_other_b = enc_stride;
+                g2.ep_other_s = (u64)d * N;
+                g2.ep_other2 = prod;
+                g2.ep_other2_b = (u64)2 * rns * N;
+                g2.ep_other2_s = (u64)rns * N;
+                g2.ep_qidx2 = k - 1;
+                g2.ep_dest = rescale_out;
+                g2.ep_dest_b = out_stride;
+                g2.ep_dest_s = (u64)(d - 1) * N;
+                g2.ep_S = 2;
+                g2.ep_acc = 0;
+                g2.ep_qidx = d - 1;
+                return launch_ntt_ex(ctx, true, tmp, ident, d - 1, batch * 2, true, (u64)(d - 1) * N, 1, false, s, false, &g2);
             }
             if (ckks && log_n >= 12)
             {

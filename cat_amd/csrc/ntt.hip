@@ -68,6 +68,13 @@ namespace
         const u64 *half_mod;  // [kdim][kdim]: (q_a >> 1) mod q_b
         const MulOp *inv_mod; // [kdim][kdim]: q_a^-1 mod q_b
         u32 kdim;
+        // second "round" source and two-term epilogue (NttFuse, relinearize + rescale in one transform)
+        const u64 *src2;
+        u64 src2_stride;
+        u32 src2_qidx;
+        u32 ep_qidx2;
+        const u64 *ep_other2;
+        u64 ep_other2_b, ep_other2_s;
     };
 
     struct Where
@@ -192,6 +199,41 @@ namespace
             s.mode = 2;
         }
         return s;
+    }
+
+    // the second "round" source of a dual transform: src2 + poly * src2_stride, values modulo prime src2_qidx
+    __device__ __forceinline__ Source source2(const NttArgs &a, const Where &w, u64 extra)
+    {
+        Source s;
+        const NttMod m = a.mods[w.mod], Q = a.mods[a.src2_qidx];
+        s.q = m.q;
+        s.ratio1 = m.ratio1;
+        s.p = a.src2 + (u64)w.poly * a.src2_stride + extra;
+        s.Q = Q.q;
+        s.Qratio1 = Q.ratio1;
+        s.half = Q.q >> 1;
+        s.fix = m.q - a.half_mod[a.src2_qidx * a.kdim + w.mod];
+        s.reduce2 = Q.q > m.q;
+        s.close = false;
+        s.mode = 2;
+        return s;
+    }
+
+    // DUAL: x = round(src; Q) * Q^-1 + round(src2; Q2), both "round" sources of NttFuse (< 3q, canonical product)
+    template <class Index>
+    __device__ __forceinline__ void load16_dual(u64 (&x)[16], const Source &in1, const Source &in2, const MulOp &inv,
+                                                Index index)
+    {
+        u64 y[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+        {
+            x[e] = in1.p[index(e)];
+            y[e] = in2.p[index(e)];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            x[e] = mul_shoup(in1.derive(x[e]), inv.op, inv.quo, in1.q) + in2.derive(y[e]);
     }
 
     // ---- arithmetic policies ----------------------------------------------------------------------------
@@ -454,7 +496,7 @@ namespace
     }
 
     // ---- forward, pass 1: columns ----------------------------------------------------------------------
-    template <class P, int LOGN1>
+    template <class P, int LOGN1, bool DUAL = false>
     __global__ __launch_bounds__(256) void ntt_fwd_cols(NttArgs a)
     {
         constexpr int K1 = LOGN1 - 4;          // stages done in round 1
@@ -476,7 +518,11 @@ namespace
         u64 x[16];
         if (K1 > 0)
         {
-            in.load16(x, [&](int e) { return ((e >> (4 - K1)) * 16 + tau * SUB + (e & (SUB - 1))) * ROW_LEN + c; });
+            auto idx = [&](int e) { return ((e >> (4 - K1)) * 16 + tau * SUB + (e & (SUB - 1))) * ROW_LEN + c; };
+            if (DUAL)
+                load16_dual(x, in, source2(a, w, w.tile * C), a.inv_mod[a.src_qidx * a.kdim + w.mod], idx);
+            else
+                in.load16(x, idx);
             if (std::is_base_of<Fast, P>::value)
                 __syncthreads(); // staged twiddles visible
             if (K1 > 0) fwd_stage16<P, 0, col_guard<P>(0)>(x, tw, 1, m);
@@ -496,7 +542,11 @@ namespace
         }
         else
         {
-            in.load16(x, [&](int l) { return (tau * 16 + l) * ROW_LEN + c; });
+            auto idx = [&](int l) { return (tau * 16 + l) * ROW_LEN + c; };
+            if (DUAL)
+                load16_dual(x, in, source2(a, w, w.tile * C), a.inv_mod[a.src_qidx * a.kdim + w.mod], idx);
+            else
+                in.load16(x, idx);
             if (std::is_base_of<Fast, P>::value)
                 __syncthreads();
         }
@@ -563,6 +613,19 @@ namespace
             u64 *dest = a.ep_dest + b * a.ep_dest_b + si * a.ep_dest_s + in_limb;
             const MulOp inv = a.inv_mod[a.ep_qidx * a.kdim + w.mod];
             const u64 q4 = m.q << 2;
+            if (a.ep_other2)
+            {
+                // two-term form: dest = ((other + other2 * Q2^-1) + 4q - t) * Q^-1, other and other2 canonical
+                const u64 *other2 = a.ep_other2 + b * a.ep_other2_b + si * a.ep_other2_s + in_limb;
+                const MulOp inv2 = a.inv_mod[a.ep_qidx2 * a.kdim + w.mod];
+#pragma unroll
+                for (int h = 0; h < 16; ++h)
+                {
+                    const u64 base_v = other[h * 16 + t] + mul_shoup(other2[h * 16 + t], inv2.op, inv2.quo, m.q);
+                    dest[h * 16 + t] = mul_shoup(base_v + q4 - s[h * 17 + t], inv.op, inv.quo, m.q);
+                }
+                return;
+            }
 #pragma unroll
             for (int h = 0; h < 16; ++h)
             {
@@ -949,7 +1012,9 @@ namespace
     template <class P, int LOGN1>
     void launch_cols(bool fwd, const NttArgs &a, u32 blocks, hipStream_t s)
     {
-        if (fwd)
+        if (fwd && a.src2)
+            hipLaunchKernelGGL((ntt_fwd_cols<P, LOGN1, true>), dim3(blocks), dim3(256), 0, s, a);
+        else if (fwd)
             hipLaunchKernelGGL((ntt_fwd_cols<P, LOGN1>), dim3(blocks), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL((ntt_inv_cols<typename std::conditional<P::WIDE, Fast, P>::type, LOGN1>), dim3(blocks),
@@ -1086,6 +1151,11 @@ namespace cat
         a.half_mod = ctx->d_half_mod;
         a.inv_mod = ctx->d_inv_mod;
         a.kdim = ctx->k;
+        a.src2 = nullptr;
+        a.src2_stride = 0;
+        a.src2_qidx = a.ep_qidx2 = 0;
+        a.ep_other2 = nullptr;
+        a.ep_other2_b = a.ep_other2_s = 0;
         if (fuse)
         {
             // inverse transforms take only the out-of-place source (src_kind 0, N >= 4096, one modulus per limb)
@@ -1107,6 +1177,18 @@ namespace cat
             a.ep_S = fuse->ep_S;
             a.ep_acc = (u32)fuse->ep_acc;
             a.ep_qidx = fuse->ep_qidx;
+            // the dual form: a second round source and the two-term epilogue come together, on a forward transform
+            // whose first source is a round source
+            if ((fuse->src2 != nullptr) != (fuse->ep_other2 != nullptr) ||
+                (fuse->src2 && (!forward || fuse->src_kind != 1 || !fuse->src || !fuse->ep_dest || fuse->ep_acc || exact)))
+                return fail(CAT_ERR_LOGIC, "unsupported fused transform");
+            a.src2 = fuse->src2;
+            a.src2_stride = fuse->src2_stride;
+            a.src2_qidx = fuse->src2_qidx;
+            a.ep_qidx2 = fuse->ep_qidx2;
+            a.ep_other2 = fuse->ep_other2;
+            a.ep_other2_b = fuse->ep_other2_b;
+            a.ep_other2_s = fuse->ep_other2_s;
         }
         // N = 2 has odd-aligned twiddle groups nowhere, but keep the tiny sizes on the exact path: nothing to gain
         if (exact || ctx->log_n < 2)

@@ -281,6 +281,43 @@ def test_ckks_multiply_relinearize_rescale_chain(cat, oracle, log_n, bits):
     ctx.close()
 
 
+@pytest.mark.parametrize("log_n,bits,scheme_name", [
+    (12, [50, 40, 40, 50], "ckks"),
+    (13, [60, 40, 40, 60], "ckks"),
+    (12, [60, 60, 60, 60, 60], "ckks"),
+    (12, [61, 61, 61, 61], "ckks"),       # 61-bit primes: the narrow lazy ranges
+    (12, [30, 45, 30, 55], "ckks"),       # primes of very different sizes: both reduce branches of the round sources
+    (10, [30, 27, 30], "ckks"),           # N < 4096: the two steps one after the other
+    (12, [40, 40, 40, 41], "bfv"),
+    (12, [50, 40, 40, 50], "bgv"),
+])
+def test_relinearize_rescale_fused_equals_the_two_calls(cat, oracle, log_n, bits, scheme_name):
+    """cat_relinearize_rescale: one forward transform per limb serves the mod-down and the rescale correction (CKKS,
+    N >= 4096); the words must equal relinearize followed by rescale_to_next / mod_switch_to_next, every level."""
+    n = 1 << log_n
+    scheme = {"ckks": (oracle.SCHEME_CKKS, cat.SCHEME_CKKS), "bfv": (oracle.SCHEME_BFV, cat.SCHEME_BFV),
+              "bgv": (oracle.SCHEME_BGV, cat.SCHEME_BGV)}[scheme_name]
+    t = 0 if scheme_name == "ckks" else 65537
+    if bits == [61, 61, 61, 61]:
+        primes = list(reversed(oracle.get_primes(2 * n, 61, 4)))
+    else:
+        primes = oracle.coeff_modulus_create(n, bits)
+    octx = oracle.Context(log_n, primes, scheme[0], t)
+    ctx = cat.Context(log_n, primes, scheme[1], t)
+    k = len(primes)
+    rk = octx.relin_key(octx.secret_key(31), 32)
+    drk = dev(rk)
+    for batch in (1, 5):
+        for L in range(k - 1, 1, -1):
+            ct3 = np.stack([octx.uniform(L, 3, 6000 + 10 * L + b) for b in range(batch)])
+            exp = np.stack([octx.rescale(octx.relinearize(ct3[b], rk)) for b in range(batch)])
+            got = host(ctx.relinearize_rescale(dev(ct3), drk))
+            assert (got == exp).all(), f"L={L} batch={batch}"
+    with pytest.raises(ValueError):
+        ctx.relinearize_rescale(dev(octx.uniform(1, 3, 1)[None]), drk)  # end of modulus switching chain reached
+    ctx.close()
+
+
 def test_switch_key_direct_and_rotate(cat, oracle):
     log_n = 12
     n = 1 << log_n
