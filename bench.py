@@ -133,12 +133,19 @@ def main():
     prod = torch.empty((B, 3, L, N), dtype=torch.int64, device=device)
     out = torch.empty((B, 2, L - 1, N), dtype=torch.int64, device=device)
 
+    two_calls = os.environ.get("CAT_BENCH_TWO_CALLS") is not None  # A/B: relinearize and rescale as separate calls
+
     def step():
         ctx.ckks_multiply(x, y, out=prod)          # Evaluator::multiply_inplace   (evaluator.cpp:569)
-        ctx.relinearize(prod, key)                 # Evaluator::relinearize_inplace (evaluator.cpp:1144)
-        # the reference's resize to size 2 (evaluator.cpp:1191) is a no-op on the buffer: rescale reads the
-        # first two polynomials of every size-3 slot in place
-        ctx.rescale_strided(prod, 2, out)          # Evaluator::rescale_to_next    (evaluator.cpp:1481)
+        if two_calls:
+            ctx.relinearize(prod, key)             # Evaluator::relinearize_inplace (evaluator.cpp:1144)
+            # the reference's resize to size 2 (evaluator.cpp:1191) is a no-op on the buffer: rescale reads the
+            # first two polynomials of every size-3 slot in place
+            ctx.rescale_strided(prod, 2, out)      # Evaluator::rescale_to_next    (evaluator.cpp:1481)
+        else:
+            # the same two reference calls through the fused entry point: identical words (checked against the
+            # oracle's relinearize + rescale below), one forward transform per limb instead of two
+            ctx.relinearize_rescale(prod, key, out=out)
 
     for _ in range(args.warmup):
         step()
