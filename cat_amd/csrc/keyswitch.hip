@@ -384,6 +384,76 @@ namespace
         }
     }
 
+    // ---- relinearize + rescale tail (launch_switch_key with rescale_out) -------------------------------------
+    struct TailArgs
+    {
+        const u64 *prod; // [batch][2][d+1][N]
+        const u64 *enc;  // [batch][2][d][N], enc_stride2 vectors apart
+        u64 *buf;        // [batch*2][2][N]: {special-prime product, enc[d-1] + prod[d-1] P^-1}
+        const DevMod *mods;
+        const MulOp *inv_mod;
+        const u64 *half_mod;
+        u32 d, k, log_n;
+        u64 enc_stride2;
+        u64 total2; // batch*2*N/2
+    };
+
+    // buf[p][0] = prod[p][d];  buf[p][1] = enc[p][d-1] + prod[p][d-1] * P^-1 mod q_{d-1}
+    __global__ __launch_bounds__(256) void tail_prepare_kernel(TailArgs g)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1);
+        const u64 q = g.mods[g.d - 1].q;
+        const MulOp pinv = g.inv_mod[(g.k - 1) * g.k + (g.d - 1)];
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 p = i >> (g.log_n - 1); // b*2 + comp
+            const ulonglong2 *pr = reinterpret_cast<const ulonglong2 *>(g.prod) + ((p * (g.d + 1)) << (g.log_n - 1)) + c;
+            const ulonglong2 sp = pr[(u64)g.d << (g.log_n - 1)], pl = pr[(u64)(g.d - 1) << (g.log_n - 1)];
+            const ulonglong2 e = reinterpret_cast<const ulonglong2 *>(g.enc)[(p >> 1) * g.enc_stride2 +
+                                                                            ((((p & 1) * g.d) + g.d - 1) << (g.log_n - 1)) + c];
+            ulonglong2 u;
+            u.x = add_mod(e.x, mul_shoup(pl.x, pinv.op, pinv.quo, q), q);
+            u.y = add_mod(e.y, mul_shoup(pl.y, pinv.op, pinv.quo, q), q);
+            ulonglong2 *o = reinterpret_cast<ulonglong2 *>(g.buf) + ((p * 2) << (g.log_n - 1)) + c;
+            o[0] = sp;
+            o[n2] = u;
+        }
+    }
+
+    // after the inverse transforms of both limbs of buf: buf[p][1] <- buf[p][1] - round_{q_{d-1}}(buf[p][0]) * P^-1,
+    // the inverse transform of the relinearized last limb (the forward transform of the mod-down correction and
+    // this inverse transform cancel)
+    __global__ __launch_bounds__(256) void tail_last_kernel(TailArgs g)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1);
+        const DevMod P = g.mods[g.k - 1], m = g.mods[g.d - 1];
+        const u64 half = P.q >> 1;
+        const u64 fix = m.q - g.half_mod[(g.k - 1) * g.k + (g.d - 1)];
+        const MulOp pinv = g.inv_mod[(g.k - 1) * g.k + (g.d - 1)];
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 p = i >> (g.log_n - 1);
+            ulonglong2 *o = reinterpret_cast<ulonglong2 *>(g.buf) + ((p * 2) << (g.log_n - 1)) + c;
+            ulonglong2 v = o[0];
+            const ulonglong2 u = o[n2];
+            v.x = barrett64(v.x + half, P.q, P.ratio1);
+            v.y = barrett64(v.y + half, P.q, P.ratio1);
+            if (P.q > m.q)
+            {
+                v.x = barrett64(v.x, m.q, m.ratio1);
+                v.y = barrett64(v.y, m.q, m.ratio1);
+            }
+            ulonglong2 r;
+            r.x = sub_mod(u.x, mul_shoup(v.x + fix, pinv.op, pinv.quo, m.q), m.q);
+            r.y = sub_mod(u.y, mul_shoup(v.y + fix, pinv.op, pinv.quo, m.q), m.q);
+            o[n2] = r;
+        }
+    }
+
     // ---- rescale ------------------------------------------------------------------------------------------
     struct RescaleArgs
     {
@@ -556,7 +626,7 @@ namespace cat
         const size_t w_ext = (size_t)batch * rns * d * N;
         const size_t w_prod = (size_t)batch * 2 * rns * N;
         const size_t w_tmp = (size_t)batch * 2 * d * N;
-        const size_t w_last = rescale_out ? (size_t)batch * 2 * N : 0;
+        const size_t w_last = rescale_out ? (size_t)batch * 2 * 2 * N : 0;
         u64 *ws = (u64 *)workspace(ctx, (w_target + w_ext + w_prod + w_tmp + w_last) * sizeof(u64));
         if (!ws)
             return CAT_ERR_NOMEM;
@@ -659,8 +729,10 @@ namespace cat
             LimbMap mp{};
             mp.id[0] = (unsigned char)(k - 1);
             // the BGV branch transforms back fully (:2724), the others lazily (:2763)
-            cat_status st = launch_ntt_ex(ctx, false, prod + (size_t)d * N, mp, 1, batch * 2, !bgv, (u64)rns * N, 1,
-                                          false, s);
+            // (with rescale_out the special limb is transformed together with the last limb, below)
+            cat_status st = CAT_OK;
+            if (!rescale_out)
+                st = launch_ntt_ex(ctx, false, prod + (size_t)d * N, mp, 1, batch * 2, !bgv, (u64)rns * N, 1, false, s);
             if (st != CAT_OK)
                 return st;
             DownArgs g;
@@ -712,46 +784,40 @@ namespace cat
                 // r1 = the mod-down round source (from INTT_P of the special limb), r2 = the rescale round source
                 // (from INTT of enc'[d-1], util/rns.cpp:857-878); the transform is linear, so
                 //   out[j] = (enc[j] + prod[j] P^-1 - NTT(r1_j P^-1 + r2_j)) q_last^-1   (mod q_j, canonical).
-                // (a) the last limb alone, as in the unfused mod-down: enc'[d-1]
-                NttFuse f;
-                f.src = prod + (size_t)d * N;
-                f.src_stride = (u64)rns * N;
-                f.src_kind = 1;
-                f.src_qidx = k - 1;
-                f.ep_other = prod + (size_t)(d - 1) * N;
-                f.ep_other_b = (u64)2 * rns * N;
-                f.ep_other_s = (u64)rns * N;
-                f.ep_dest = enc + (size_t)(d - 1) * N;
-                f.ep_dest_b = enc_stride;
-                f.ep_dest_s = (u64)d * N;
-                f.ep_S = 2;
-                f.ep_acc = 1;
-                f.ep_qidx = k - 1;
-                LimbMap ml{};
-                ml.id[0] = (unsigned char)(d - 1);
-                st = launch_ntt_ex(ctx, true, tmp, ml, 1, batch * 2, true, (u64)N, 1, false, s, false, &f);
-                if (st != CAT_OK)
-                    return st;
-                // (b) its canonical inverse transform, gathered per polynomial (rns.cpp:845-855)
-                RescaleArgs r{};
-                r.in = enc;
-                r.L = d;
-                r.log_n = log_n;
-                r.size = 2;
-                r.in_stride2 = enc_stride / 2;
-                hipLaunchKernelGGL(gather_last_kernel, dim3(grid_for(w_last / 2)), dim3(256), 0, s, r, last, (u64)w_last / 2);
+                // The last limb first: the rescale needs INTT(enc'[d-1]), and
+                //   INTT(enc'[d-1]) = INTT(enc[d-1] + prod[d-1] P^-1) - r1_{d-1} P^-1
+                // (the forward transform of the correction and this inverse transform cancel), so one batched inverse
+                // transform over {special limb, u = enc[d-1] + prod[d-1] P^-1} feeds both round sources.
+                TailArgs ta;
+                ta.prod = prod;
+                ta.enc = enc;
+                ta.buf = last;
+                ta.mods = ctx->d_mods;
+                ta.inv_mod = ctx->d_inv_mod;
+                ta.half_mod = ctx->d_half_mod;
+                ta.d = d;
+                ta.k = k;
+                ta.log_n = log_n;
+                ta.enc_stride2 = enc_stride / 2;
+                ta.total2 = (u64)batch * 2 * N / 2;
+                hipLaunchKernelGGL(tail_prepare_kernel, dim3(grid_for(ta.total2)), dim3(256), 0, s, ta);
                 CAT_HIP(hipGetLastError());
-                st = launch_ntt(ctx, false, last, ml, 1, batch * 2, false, s);
+                LimbMap m2{};
+                m2.id[0] = (unsigned char)(k - 1);
+                m2.id[1] = (unsigned char)(d - 1);
+                st = launch_ntt(ctx, false, last, m2, 2, batch * 2, false, s);
                 if (st != CAT_OK)
                     return st;
+                hipLaunchKernelGGL(tail_last_kernel, dim3(grid_for(ta.total2)), dim3(256), 0, s, ta);
+                CAT_HIP(hipGetLastError());
                 // (c) the remaining d-1 limbs: dual source, two-term epilogue
                 NttFuse g2;
-                g2.src = prod + (size_t)d * N;
-                g2.src_stride = (u64)rns * N;
+                g2.src = last;
+                g2.src_stride = (u64)2 * N;
                 g2.src_kind = 1;
                 g2.src_qidx = k - 1;
-                g2.src2 = last;
-                g2.src2_stride = N;
+                g2.src2 = last + N;
+                g2.src2_stride = (u64)2 * N;
                 g2.src2_qidx = d - 1;
                 g2.ep_other = enc;
                 g2.ep_other_b = enc_stride;
