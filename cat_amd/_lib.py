@@ -59,6 +59,7 @@ SIGNATURES = {
     "cat_apply_galois_ntt": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "cat_apply_galois": (C.c_int, [vp, vp, vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, vp]),
     "cat_apply_galois_inplace": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp]),
+    "cat_apply_galois_rescale": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_bfv_multiply": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_bfv_base_Bsk_size": (C.c_uint32, [vp, C.c_uint32]),
     "cat_bfv_base_Bsk": (C.c_int, [vp, C.c_uint32, u64p]),

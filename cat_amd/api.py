@@ -290,5 +290,12 @@ class Context:
         _check(self.lib.cat_apply_galois_inplace(self.h, self._p(ct), elt, self._p(key), L, b, self._stream()))
         return ct
 
+    def apply_galois_rescale(self, ct, elt, key, out=None):
+        """ct: [batch, 2, L, N] (scratch afterwards) -> [batch, 2, L-1, N] = rescale(apply_galois(ct))"""
+        b, _, L, _ = ct.shape
+        out = torch.empty((b, 2, L - 1, self.n), dtype=torch.int64, device=ct.device) if out is None else out
+        _check(self.lib.cat_apply_galois_rescale(self.h, self._p(ct), elt, self._p(key), self._p(out), L, b, self._stream()))
+        return out
+
     def rotate_vector(self, ct, step, key):
         return self.apply_galois_inplace(ct, galois_elt_from_step(self.log_n, step), key)

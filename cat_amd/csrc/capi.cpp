@@ -786,8 +786,34 @@ cat_status cat_apply_galois(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uin
     return launch_galois(ctx, false, (const u64 *)in, (u64 *)out, elt, map, nl ? nl : 1, nl ? np : 0, (hipStream_t)s);
 }
 
+static cat_status galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, const uint64_t *key, uint32_t L, uint32_t batch,
+                                 cat_stream s, uint64_t *rescale_out);
+
 cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, const uint64_t *key, uint32_t L,
                                     uint32_t batch, cat_stream s)
+{
+    return galois_inplace(ctx, ct, elt, key, L, batch, s, nullptr);
+}
+
+cat_status cat_apply_galois_rescale(cat_ctx *ctx, uint64_t *ct, uint32_t elt, const uint64_t *key, uint64_t *out, uint32_t L,
+                                    uint32_t batch, cat_stream s)
+{
+    if (!out)
+        return fail(CAT_ERR_INVALID_ARG, "destination is not valid");
+    if (ctx && L < 2)
+        return fail(CAT_ERR_INVALID_ARG, "end of modulus switching chain reached");
+    if (ctx && batch)
+    {
+        const u64 *in_end = (const u64 *)ct + (size_t)batch * 2 * L * ctx->n,
+                  *out_end = (const u64 *)out + (size_t)batch * 2 * (L - 1) * ctx->n;
+        if (ct && !(out_end <= (const u64 *)ct || in_end <= (const u64 *)out))
+            return fail(CAT_ERR_INVALID_ARG, "destination must not alias the inputs");
+    }
+    return galois_inplace(ctx, ct, elt, key, L, batch, s, out);
+}
+
+static cat_status galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, const uint64_t *key, uint32_t L, uint32_t batch,
+                                 cat_stream s, uint64_t *rescale_out)
 {
     cat_status st = check(ctx);
     if (st != CAT_OK)
@@ -806,7 +832,7 @@ cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, co
     // target perm(c1) in place, one ciphertext stride apart (:2410-2449).  The permuted copy must survive
     // launch_switch_key's own workspace use, so it is carved from the same block, after the key-switch region.
     const size_t N = ctx->n, ctw = (size_t)2 * L * N;
-    const size_t ks_words = (size_t)batch * ((size_t)L + (size_t)(L + 1) * L + 2 * (L + 1) + 2 * L) * N;
+    const size_t ks_words = (size_t)batch * ((size_t)L + (size_t)(L + 1) * L + 2 * (L + 1) + 2 * L + 4) * N;
     u64 *ws = (u64 *)workspace(ctx, (ks_words + (size_t)batch * ctw) * sizeof(u64));
     if (!ws)
         return CAT_ERR_NOMEM;
@@ -819,7 +845,15 @@ cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, co
     st = launch_copy_c0_zero_c1(ctx, perm, (u64 *)ct, L, batch, (hipStream_t)s);
     if (st != CAT_OK)
         return st;
-    return launch_switch_key(ctx, (u64 *)ct, tgt, (const u64 *)key, L, batch, ctw, ctw, (hipStream_t)s);
+    if (!rescale_out)
+        return launch_switch_key(ctx, (u64 *)ct, tgt, (const u64 *)key, L, batch, ctw, ctw, (hipStream_t)s);
+    if (ctx->scheme == CAT_SCHEME_CKKS && ctx->log_n >= 12)
+        return launch_switch_key(ctx, (u64 *)ct, tgt, (const u64 *)key, L, batch, ctw, ctw, (hipStream_t)s,
+                                 (u64 *)rescale_out, (size_t)2 * (L - 1) * N);
+    st = launch_switch_key(ctx, (u64 *)ct, tgt, (const u64 *)key, L, batch, ctw, ctw, (hipStream_t)s);
+    if (st != CAT_OK)
+        return st;
+    return launch_rescale(ctx, (const u64 *)ct, (u64 *)rescale_out, L, 2, batch, ctw, (size_t)2 * (L - 1) * N, (hipStream_t)s);
 }
 
 } // extern "C"

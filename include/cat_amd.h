@@ -208,6 +208,12 @@ cat_status cat_apply_galois(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out,
 cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *d_ct, uint32_t galois_elt, const uint64_t *d_key,
                                     uint32_t L, uint32_t batch, cat_stream s);
 
+/* apply_galois_inplace (rotate_vector) directly followed by rescale_to_next / mod_switch_to_next, as one call with the
+ * same words as the two (see cat_relinearize_rescale): d_out is batch x 2 x (L-1) x N and must not overlap d_ct, which
+ * is scratch afterwards. */
+cat_status cat_apply_galois_rescale(cat_ctx *ctx, uint64_t *d_ct, uint32_t galois_elt, const uint64_t *d_key,
+                                    uint64_t *d_out, uint32_t L, uint32_t batch, cat_stream s);
+
 /* ---- a12: Evaluator::bfv_multiply, size 2 x 2 -> 3 (evaluator.cpp:395-567) with the BEHZ tool
  * (util/rns.cpp:418-463, 903-1131).  d_x, d_y: batch x 2 x L x N coefficient form; d_out: batch x 3 x L x N. */
 cat_status cat_bfv_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, uint64_t *d_out, uint32_t L,

@@ -315,6 +315,13 @@ def test_relinearize_rescale_fused_equals_the_two_calls(cat, oracle, log_n, bits
             assert (got == exp).all(), f"L={L} batch={batch}"
     with pytest.raises(ValueError):
         ctx.relinearize_rescale(dev(octx.uniform(1, 3, 1)[None]), drk)  # end of modulus switching chain reached
+    # the same tail behind a rotation
+    elt = cat.galois_elt_from_step(log_n, 1)
+    gk = octx.galois_key(octx.secret_key(31), elt, 33)
+    for L in range(k - 1, 1, -1):
+        ct = np.stack([octx.uniform(L, 2, 7000 + 10 * L + b) for b in range(3)])
+        exp = np.stack([octx.rescale(octx.apply_galois_inplace(ct[b], elt, gk)) for b in range(3)])
+        assert (host(ctx.apply_galois_rescale(dev(ct), elt, dev(gk))) == exp).all(), f"rotate+rescale L={L}"
     ctx.close()
 
 

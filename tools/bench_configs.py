@@ -78,8 +78,7 @@ def config4(steps):
     def chain():
         cur = ct0.clone()
         for _ in range(levels):
-            ctx.rotate_vector(cur, 1, dgk)
-            cur = ctx.rescale(cur)
+            cur = ctx.apply_galois_rescale(cur, 3, dgk)  # rotate_vector(1) + rescale_to_next, the same words
         return cur
 
     got = chain()
