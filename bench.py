@@ -184,6 +184,8 @@ def main():
                         f"rescale_to_next on {B} independent ciphertext pairs per GPU per step (BASELINE config 4 "
                         "parameters, metric op)",
             "batch_per_gpu": B,
+            "calls": "cat_ckks_multiply + cat_relinearize + cat_rescale_strided" if two_calls
+                     else "cat_ckks_multiply + cat_relinearize_rescale (the words of relinearize then rescale_to_next)",
             "parallelism": f"batch-sharded x{world}, no data-path collective",
             "algorithmic_bytes_per_op": bytes_per_op,
             "op_hbm_floor_frac": (ops_per_s / world) * bytes_per_op / (HBM_PEAK_GBS * 1e9),
