@@ -160,3 +160,51 @@ def test_seal_keys_and_encryptions_decrypt(oracle, scheme_name):
     rel = ctx.relinearize(prod, rk)
     exp = negacyclic_mul(m1, m2)
     assert dec(rel, q, scale * scale) == [v % t if t else v for v in exp]
+
+
+@pytest.mark.parametrize("scheme_name,t", [("bfv", 65537), ("bgv", 65537), ("bfv", 1032193), ("bgv", 786433)])
+def test_plaintext_encryption_and_decryption_tails(oracle, scheme_name, t):
+    """oracle/seal_plain.py (scaling variant, BGV lift, decrypt_scale_and_round, decrypt_modt) on top of the C oracle:
+    decrypt(encrypt(m)) == m, products and rotations decrypt to the expected plaintexts, after a modulus switch too."""
+    from oracle import seal_plain as sp
+
+    scheme = oracle.SCHEME_BFV if scheme_name == "bfv" else oracle.SCHEME_BGV
+    bfv = scheme == oracle.SCHEME_BFV
+    primes = oracle.coeff_modulus_create(N, [40, 36, 36, 40])
+    ctx = oracle.Context(LOG_N, primes, scheme, t)
+    k = len(primes)
+    L = k - 1
+    q = primes[:L]
+    gamma = oracle.get_primes(2 * N, 61, 2)[1]  # util/rns.cpp:625-631
+    sk = ctx.seal_secret_key(SEED)
+    rng = np.random.default_rng(9)
+    m1 = [int(v) for v in rng.integers(0, t, N)]
+    m2 = [int(v) for v in rng.integers(0, t, N)]
+
+    def enc(m, seed):
+        z = ctx.seal_encrypt_zero(L, seed, sk=sk)
+        add = sp.bfv_scale_plain(m, q, t) if bfv else np.stack(
+            [oracle.NTTTables(LOG_N, q[i]).forward(sp.bgv_lift_plain(m, q, t)[i]) for i in range(L)])
+        for i in range(L):
+            z[0, i] = (z[0, i].astype(object) + add[i].astype(object)) % q[i]
+        return z.astype(np.uint64)
+
+    def dec(ct, qs, cf=1):
+        ph = ctx.seal_dot_product(sk, ct, not bfv)
+        if bfv:
+            return sp.bfv_decrypt_scale_and_round(ph, qs, t, gamma)
+        ph = np.stack([oracle.NTTTables(LOG_N, qs[i]).inverse(ph[i]) for i in range(len(qs))])
+        return sp.bgv_decrypt_modt(ph, qs, t, cf)
+
+    c1, c2 = enc(m1, [s + 1 for s in SEED]), enc(m2, [s + 2 for s in SEED])
+    assert dec(c1, q) == m1 and dec(c2, q) == m2
+    rk = ctx.seal_relin_key(sk, [s + 3 for s in SEED])
+    prod = ctx.relinearize(ctx.bfv_multiply(c1, c2) if bfv else ctx.ckks_multiply(c1, c2), rk)
+    exp = [v % t for v in negacyclic_mul(m1, m2)]
+    assert dec(prod, q) == exp
+    sw = ctx.rescale(prod)  # mod_switch_to_next
+    cf = 1 if bfv else pow(q[-1], -1, t)  # evaluator.cpp:1274-1279
+    assert dec(sw, q[:-1], cf) == exp
+    elt = 3
+    rot = ctx.apply_galois_inplace(c1, elt, ctx.seal_galois_key(sk, elt, [s + 4 for s in SEED]))
+    assert dec(rot, q) == [v % t for v in automorphism(m1, elt)]
