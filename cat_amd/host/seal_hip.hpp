@@ -499,6 +499,23 @@ namespace seal
             // storage is borrowed from Ciphertext (2 polys allocated, the first one used)
             buf_.is_ntt_form() = true;
         }
+        // A BFV / BGV plaintext (plaintext.h): up to N coefficients modulo t on the HOST, parms_id zero, not NTT form.
+        // It reaches the device inside Encryptor::encrypt and comes back from Decryptor::decrypt.
+        Plaintext() = default;
+        explicit Plaintext(std::vector<std::uint64_t> coeffs) : coeffs_(std::move(coeffs))
+        {}
+        std::size_t coeff_count() const noexcept
+        {
+            return coeffs_.size();
+        }
+        const std::vector<std::uint64_t> &data() const noexcept
+        {
+            return coeffs_;
+        }
+        std::vector<std::uint64_t> &data() noexcept
+        {
+            return coeffs_;
+        }
         void upload(const std::uint64_t *host)
         {
             std::vector<std::uint64_t> tmp(buf_.words(), 0);
@@ -581,6 +598,7 @@ namespace seal
 
     private:
         Ciphertext buf_;
+        std::vector<std::uint64_t> coeffs_;
     };
 
     // KSwitchKeys::data()[index] = vector<PublicKey>, one PublicKey per decomposition prime, each 2 x k x N

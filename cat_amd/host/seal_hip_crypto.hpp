@@ -9,11 +9,10 @@
 // public-key encryption) runs on the device through the C ABI.  A level is named by its limb count L as in
 // seal_hip.hpp; the key level has all k primes.
 //
-// Not restated: plaintext encoding and the
-// BFV/BGV plaintext lift (`encrypt(plain)` is the CKKS branch; BFV/BGV callers use encrypt_zero and the phase);
-// the RNS tail of BFV/BGV decryption (RNSTool::decrypt_scale_and_round / decrypt_modt, out of scope in SURVEY
-// section 2) -- Decryptor exposes the phase c0 + c1 s + ... of any scheme and finishes CKKS, whose plaintext IS
-// the phase.
+// BFV / BGV plaintexts are host coefficient vectors modulo t: their scaling (util/scalingvariant.cpp:69-113) or
+// lift (encryptor.cpp:261-304) and the RNS tail of decryption (RNSTool::decrypt_scale_and_round, decrypt_modt,
+// util/rns.cpp:466-539, 1133-1252) are small per-coefficient host loops around the device work.  Not restated:
+// the encoders (CKKSEncoder, BatchEncoder).
 #pragma once
 
 #include "seal_hip.hpp"
@@ -68,6 +67,187 @@ namespace seal
             cat_ctx *h_;
             std::uint64_t *d_ = nullptr;
             std::size_t words_;
+        };
+
+        // ---- small multi-word helpers (little-endian words) for the per-level plaintext constants -------------------
+        using u128 = unsigned __int128;
+        inline std::vector<std::uint64_t> mp_mul_word(const std::vector<std::uint64_t> &a, std::uint64_t w)
+        {
+            std::vector<std::uint64_t> r(a.size() + 1, 0);
+            std::uint64_t carry = 0;
+            for (std::size_t i = 0; i < a.size(); ++i)
+            {
+                const u128 t = (u128)a[i] * w + carry;
+                r[i] = (std::uint64_t)t;
+                carry = (std::uint64_t)(t >> 64);
+            }
+            r[a.size()] = carry;
+            return r;
+        }
+        inline std::uint64_t mp_mod_word(const std::vector<std::uint64_t> &a, std::uint64_t p)
+        {
+            u128 r = 0;
+            for (std::size_t i = a.size(); i--;)
+                r = ((r << 64) | a[i]) % p;
+            return (std::uint64_t)r;
+        }
+        inline std::vector<std::uint64_t> mp_div_word(const std::vector<std::uint64_t> &a, std::uint64_t w)
+        {
+            std::vector<std::uint64_t> q(a.size(), 0);
+            u128 r = 0;
+            for (std::size_t i = a.size(); i--;)
+            {
+                const u128 cur = (r << 64) | a[i];
+                q[i] = (std::uint64_t)(cur / w);
+                r = cur % w;
+            }
+            return q;
+        }
+        inline std::vector<std::uint64_t> mp_product(const std::vector<std::uint64_t> &vals, std::size_t skip)
+        {
+            std::vector<std::uint64_t> r{ 1 };
+            for (std::size_t i = 0; i < vals.size(); ++i)
+                if (i != skip)
+                    r = mp_mul_word(r, vals[i]);
+            return r;
+        }
+        inline std::uint64_t mul_mod(std::uint64_t a, std::uint64_t b, std::uint64_t p)
+        {
+            return (std::uint64_t)((u128)a * b % p);
+        }
+        inline bool try_invert_mod(std::uint64_t a, std::uint64_t m, std::uint64_t &out)
+        {
+            __int128 r0 = m, r1 = a % m, t0 = 0, t1 = 1;
+            while (r1)
+            {
+                const __int128 q = r0 / r1, r2 = r0 - q * r1, t2 = t0 - q * t1;
+                r0 = r1, r1 = r2, t0 = t1, t1 = t2;
+            }
+            if (r0 != 1)
+                return false;
+            out = (std::uint64_t)(t0 < 0 ? t0 + m : t0);
+            return true;
+        }
+
+        // What SEALContext::ContextData and RNSTool hold for the plaintext side of one level (context.cu:441-491,
+        // util/rns.cpp:640-765): host constants, built when an Encryptor / Decryptor first meets the level.
+        struct PlainTools
+        {
+            std::vector<std::uint64_t> q;            // the level's primes
+            std::uint64_t t = 0, gamma = 0;
+            std::uint64_t q_mod_t = 0, threshold = 0; // coeff_modulus_mod_plain_modulus, plain_upper_half_threshold
+            std::vector<std::uint64_t> div;          // coeff_div_plain_modulus: floor(q / t) mod q_i
+            std::vector<std::uint64_t> inv_punc;     // ((q / q_i) mod q_i)^-1 mod q_i
+            std::vector<std::uint64_t> to_t, to_gamma; // (q / q_i) mod t, mod gamma
+            std::vector<std::uint64_t> prod_t_gamma; // t gamma mod q_i
+            std::uint64_t neg_inv_q_t = 0, neg_inv_q_gamma = 0, inv_gamma_t = 0;
+
+            PlainTools(const std::vector<std::uint64_t> &primes, std::uint64_t plain_modulus, std::uint64_t gamma_prime)
+                : q(primes), t(plain_modulus), gamma(gamma_prime)
+            {
+                const std::vector<std::uint64_t> Q = mp_product(q, (std::size_t)-1);
+                q_mod_t = mp_mod_word(Q, t);
+                threshold = (t + 1) >> 1;
+                const std::vector<std::uint64_t> Q_div_t = mp_div_word(Q, t);
+                for (std::size_t i = 0; i < q.size(); ++i)
+                {
+                    div.push_back(mp_mod_word(Q_div_t, q[i]));
+                    const std::vector<std::uint64_t> punc = mp_product(q, i);
+                    std::uint64_t inv = 0;
+                    if (!try_invert_mod(mp_mod_word(punc, q[i]), q[i], inv))
+                        throw std::logic_error("invalid rns bases");
+                    inv_punc.push_back(inv);
+                    to_t.push_back(mp_mod_word(punc, t));
+                    if (gamma)
+                    {
+                        to_gamma.push_back(mp_mod_word(punc, gamma));
+                        prod_t_gamma.push_back(mul_mod(t % q[i], gamma % q[i], q[i]));
+                    }
+                }
+                if (gamma)
+                {
+                    std::uint64_t inv = 0;
+                    if (!try_invert_mod(q_mod_t, t, inv))
+                        throw std::logic_error("invalid rns bases");
+                    neg_inv_q_t = inv ? t - inv : 0;
+                    if (!try_invert_mod(mp_mod_word(Q, gamma), gamma, inv))
+                        throw std::logic_error("invalid rns bases");
+                    neg_inv_q_gamma = gamma - inv;
+                    if (!try_invert_mod(gamma % t, t, inv_gamma_t))
+                        throw std::logic_error("invalid rns bases");
+                }
+            }
+
+            // multiply_add_plain_with_scaling_variant (util/scalingvariant.cpp:69-113): out[i][idx] = round(q m / t) mod q_i
+            void scale_plain(const std::vector<std::uint64_t> &m, std::size_t n, std::uint64_t *out) const
+            {
+                std::fill(out, out + q.size() * n, 0);
+                for (std::size_t idx = 0; idx < m.size(); ++idx)
+                {
+                    const std::uint64_t fix = (std::uint64_t)(((u128)m[idx] * q_mod_t + threshold) / t);
+                    for (std::size_t i = 0; i < q.size(); ++i)
+                        out[i * n + idx] = (std::uint64_t)(((u128)m[idx] * div[i] + fix) % q[i]);
+                }
+            }
+            // the BGV lift (encryptor.cpp:261-304): the upper half of [0, t) stands for negatives; both branches of the
+            // reference (fast lift or decomposition of m + q - t) leave (m - t) mod q_i
+            void lift_plain(const std::vector<std::uint64_t> &m, std::size_t n, std::uint64_t *out) const
+            {
+                std::fill(out, out + q.size() * n, 0);
+                for (std::size_t idx = 0; idx < m.size(); ++idx)
+                    for (std::size_t i = 0; i < q.size(); ++i)
+                    {
+                        const std::uint64_t v = m[idx] % q[i];
+                        out[i * n + idx] = m[idx] >= threshold ? (v + q[i] - t % q[i]) % q[i] : v;
+                    }
+            }
+            // BaseConverter::fast_convert_array (util/rns.cpp:418-463) for one coefficient into one modulus
+            std::uint64_t convert(const std::uint64_t *temp, const std::vector<std::uint64_t> &matrix, std::uint64_t p) const
+            {
+                u128 acc = 0;
+                for (std::size_t i = 0; i < q.size(); ++i)
+                    acc = (acc + (u128)temp[i] * matrix[i]) % p;
+                return (std::uint64_t)acc;
+            }
+            // RNSTool::decrypt_scale_and_round (util/rns.cpp:1133-1201): phase [L][N] -> N coefficients modulo t
+            void decrypt_scale_and_round(const std::uint64_t *phase, std::size_t n, std::uint64_t *out) const
+            {
+                std::vector<std::uint64_t> temp(q.size());
+                const std::uint64_t gamma_div_2 = gamma >> 1;
+                for (std::size_t j = 0; j < n; ++j)
+                {
+                    for (std::size_t i = 0; i < q.size(); ++i)
+                        temp[i] = mul_mod(mul_mod(phase[i * n + j], prod_t_gamma[i], q[i]), inv_punc[i], q[i]);
+                    const std::uint64_t vt = mul_mod(convert(temp.data(), to_t, t), neg_inv_q_t, t);
+                    const std::uint64_t vg = mul_mod(convert(temp.data(), to_gamma, gamma), neg_inv_q_gamma, gamma);
+                    std::uint64_t r;
+                    if (vg > gamma_div_2)
+                        r = (vt + (gamma - vg) % t) % t;
+                    else
+                        r = (vt + t - vg % t) % t;
+                    out[j] = r ? mul_mod(r, inv_gamma_t, t) : 0;
+                }
+            }
+            // RNSTool::decrypt_modt = BaseConverter::exact_convert_array (util/rns.cpp:466-539): the rounding term is
+            // a double-precision sum in limb order, as in the reference
+            void decrypt_modt(const std::uint64_t *phase, std::size_t n, std::uint64_t *out) const
+            {
+                std::vector<std::uint64_t> temp(q.size());
+                for (std::size_t j = 0; j < n; ++j)
+                {
+                    double v = 0.0;
+                    for (std::size_t i = 0; i < q.size(); ++i)
+                    {
+                        temp[i] = mul_mod(phase[i * n + j], inv_punc[i], q[i]);
+                        v += static_cast<double>(temp[i]) / static_cast<double>(q[i]);
+                    }
+                    v += 0.5;
+                    const std::uint64_t rounded = static_cast<std::uint64_t>(v);
+                    const std::uint64_t sum = convert(temp.data(), to_t, t);
+                    const std::uint64_t vq = mul_mod(rounded % t, q_mod_t, t);
+                    out[j] = (sum + t - vq) % t;
+                }
+            }
         };
 
         inline std::vector<std::uint64_t> level_primes(const SEALContext &context, std::size_t L)
@@ -497,8 +677,35 @@ namespace seal
         }
         void encrypt_plain(const Plaintext &plain, bool is_asymmetric, Ciphertext &destination) const
         {
-            if (context_.parms().scheme() != scheme_type::ckks)
-                throw std::logic_error("unsupported: the plaintext lift of BFV/BGV is not restated; use encrypt_zero");
+            const scheme_type scheme = context_.parms().scheme();
+            if (scheme == scheme_type::bfv || scheme == scheme_type::bgv)
+            {
+                // encryptor.cpp:205-217 (BFV) and :245-318 (BGV): a fresh encryption of zero at the first level whose c0
+                // gets round(q m / t), or the transform of the lifted plaintext
+                if (plain.is_ntt_form())
+                    throw std::invalid_argument("plain cannot be in NTT form");
+                const std::size_t L = context_.first_level_size(), n = context_.poly_modulus_degree();
+                const std::uint64_t t = context_.parms().plain_modulus();
+                if (plain.coeff_count() > n)
+                    throw std::invalid_argument("plain is not valid for encryption parameters");
+                for (std::uint64_t c : plain.data())
+                    if (c >= t)
+                        throw std::invalid_argument("plain is not valid for encryption parameters");
+                encrypt_zero_internal(L, is_asymmetric, destination);
+                const detail::PlainTools tools(detail::level_primes(context_, L), t, 0);
+                std::vector<std::uint64_t> add(L * n);
+                if (scheme == scheme_type::bfv)
+                    tools.scale_plain(plain.data(), n, add.data());
+                else
+                    tools.lift_plain(plain.data(), n, add.data());
+                detail::DeviceWords d_add(context_.handle(), add);
+                if (scheme == scheme_type::bgv)
+                    detail::check(cat_ntt_forward(context_.handle(), d_add.get(), nullptr, (std::uint32_t)L, 1, 0, nullptr));
+                detail::check(cat_add(context_.handle(), destination.d_data(0), d_add.get(), destination.d_data(0), nullptr,
+                                      (std::uint32_t)L, 1, nullptr));
+                detail::check(cat_stream_sync(context_.handle(), nullptr));
+                return;
+            }
             if (!plain.is_ntt_form())
                 throw std::invalid_argument("plain must be in NTT form");
             const std::size_t L = plain.coeff_modulus_size();
@@ -559,9 +766,50 @@ namespace seal
         // of the ciphertext
         void decrypt(const Ciphertext &encrypted, Plaintext &destination)
         {
-            if (context_.parms().scheme() != scheme_type::ckks)
-                throw std::logic_error("unsupported: BFV/BGV decryption ends in the RNS tool's scale-and-round; use "
-                                       "dot_product_ct_sk_array for the phase");
+            const scheme_type scheme = context_.parms().scheme();
+            if (scheme == scheme_type::bfv || scheme == scheme_type::bgv)
+            {
+                // bfv_decrypt (decryptor.cu:672-730) / bgv_decrypt (:103-150): the phase on the device, its RNS tail
+                // (decrypt_scale_and_round / decrypt_modt and the correction factor) on the host
+                const bool bfv = scheme == scheme_type::bfv;
+                if (bfv && encrypted.is_ntt_form())
+                    throw std::invalid_argument("encrypted cannot be in NTT form");
+                if (!bfv && !encrypted.is_ntt_form())
+                    throw std::invalid_argument("encrypted must be in NTT form");
+                const std::size_t L = encrypted.coeff_modulus_size(), n = context_.poly_modulus_degree();
+                const std::uint64_t t = context_.parms().plain_modulus();
+                detail::DeviceWords d_phase(context_.handle(), L * n);
+                dot_product_ct_sk_array(encrypted, d_phase.get());
+                if (!bfv)
+                    detail::check(cat_ntt_inverse(context_.handle(), d_phase.get(), nullptr, (std::uint32_t)L, 1, 0, nullptr));
+                const std::vector<std::uint64_t> phase = d_phase.to_cpu();
+                // gamma = the second auxiliary prime of the BEHZ tool (util/rns.cpp:625-631); a BFV context lists its
+                // auxiliary primes after the coefficient primes
+                const std::uint64_t gamma = bfv ? cat_ctx_modulus(context_.handle(), (std::uint32_t)context_.key_modulus_size() + 1) : 0;
+                const detail::PlainTools tools(detail::level_primes(context_, L), t, gamma);
+                std::vector<std::uint64_t> m(n);
+                if (bfv)
+                    tools.decrypt_scale_and_round(phase.data(), n, m.data());
+                else
+                {
+                    tools.decrypt_modt(phase.data(), n, m.data());
+                    if (encrypted.correction_factor() != 1)
+                    {
+                        std::uint64_t fix = 1;
+                        if (!detail::try_invert_mod(encrypted.correction_factor(), t, fix))
+                            throw std::logic_error("invalid correction factor");
+                        for (auto &c : m)
+                            c = detail::mul_mod(c, fix, t);
+                    }
+                }
+                // the plaintext keeps its significant coefficients (decryptor.cu:724-728)
+                std::size_t count = n;
+                while (count > 1 && m[count - 1] == 0)
+                    --count;
+                m.resize(count);
+                destination = Plaintext(std::move(m));
+                return;
+            }
             if (!encrypted.is_ntt_form())
                 throw std::invalid_argument("encrypted must be in NTT form");
             if (destination.coeff_modulus_size() != encrypted.coeff_modulus_size())

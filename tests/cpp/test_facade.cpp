@@ -478,8 +478,11 @@ static void test_crypto(scheme_type scheme)
         seal::detail::DeviceWords d_ph(context.handle(), L * n);
         decryptor.dot_product_ct_sk_array(ct, d_ph.get());
         EXPECT(d_ph.to_cpu() == ph);
-        Plaintext plain(context, L);
-        EXPECT(throws<std::logic_error>([&] { decryptor.decrypt(ct, plain); }));
+        Plaintext plain;
+        decryptor.decrypt(ct, plain); // random words: any plaintext below t, never more than N coefficients
+        EXPECT(plain.coeff_count() >= 1 && plain.coeff_count() <= n);
+        for (uint64_t c : plain.data())
+            EXPECT(c < t);
         so_context_destroy(oc);
         return;
     }
@@ -746,6 +749,88 @@ static void test_serialization(const std::string &dir)
     so_context_destroy(oc);
 }
 
+// BFV / BGV with plaintexts: encrypt -> multiply -> relinearize -> mod switch -> decrypt gives the
+// negacyclic product modulo t, as the reference's Evaluator tests check (native/tests/seal/evaluator.cpp:5259-5558);
+// the ciphertexts and decrypted plaintexts are also written to `dir` for the bit-exact comparison with the oracle
+// (oracle/seal_plain.py on top of oracle/seal_oracle.c) in tests/test_gpu_facade.py.
+static void test_plain_modes(const std::string &dir, scheme_type scheme)
+{
+    const size_t n = 4096, k = 4, L = 3;
+    const int bits[4] = { 40, 40, 40, 41 };
+    const uint64_t t = 65537;
+    vec primes(4);
+    EXPECT(so_coeff_modulus_create(n, bits, 4, primes.data()) == 0);
+    const prng_seed_type seed = { 301, 302, 303, 304, 305, 306, 307, 308 };
+    EncryptionParameters parms(scheme);
+    parms.set_poly_modulus_degree(n);
+    parms.set_coeff_modulus(primes);
+    parms.set_plain_modulus(t);
+    parms.set_random_generator(std::make_shared<Blake2xbPRNGFactory>(seed));
+    SEALContext context(parms);
+    KeyGenerator keygen(context);
+    RelinKeys relin_keys(context);
+    keygen.create_relin_keys(relin_keys);
+    PublicKey public_key;
+    keygen.create_public_key(public_key);
+    Encryptor encryptor(context, public_key, keygen.secret_key());
+    Decryptor decryptor(context, keygen.secret_key());
+    Evaluator evaluator(context);
+    EXPECT(context.first_level_size() == L && k == context.key_modulus_size());
+
+    vec m1(n), m2(n / 2); // the second plaintext is shorter than N (plain.coeff_count() < N)
+    for (size_t i = 0; i < n; ++i)
+        m1[i] = (i * i * 7 + 3 * i + 11) % t;
+    for (size_t i = 0; i < m2.size(); ++i)
+        m2[i] = (i * 5 + (i % 7) * 1000 + 65000) % t;
+    Ciphertext c1, c2;
+    encryptor.encrypt_symmetric(Plaintext(m1), c1);
+    encryptor.encrypt(Plaintext(m2), c2);
+    EXPECT(c1.coeff_modulus_size() == L && c1.is_ntt_form() == (scheme == scheme_type::bgv));
+    Plaintext back;
+    decryptor.decrypt(c1, back);
+    EXPECT(back.data() == m1 && !back.is_ntt_form());
+    decryptor.decrypt(c2, back);
+    EXPECT(back.data() == m2);
+    EXPECT(throws<std::invalid_argument>([&] { encryptor.encrypt(Plaintext(vec{ t }), c2); })); // coefficient not below t
+
+    // expected product: negacyclic convolution modulo t
+    vec exp(n, 0);
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < m2.size(); ++j)
+        {
+            const uint64_t p = m1[i] * m2[j] % t;
+            const size_t d = i + j;
+            if (d < n)
+                exp[d] = (exp[d] + p) % t;
+            else
+                exp[d - n] = (exp[d - n] + t - p) % t;
+        }
+    Ciphertext prod(c1);
+    evaluator.multiply_inplace(prod, c2);
+    evaluator.relinearize_inplace(prod, relin_keys);
+    decryptor.decrypt(prod, back);
+    vec got = back.data();
+    got.resize(n, 0);
+    EXPECT(got == exp);
+    evaluator.mod_switch_to_next_inplace(prod);
+    EXPECT(prod.coeff_modulus_size() == L - 1 && (scheme == scheme_type::bfv || prod.correction_factor() != 1));
+    decryptor.decrypt(prod, back);
+    got = back.data();
+    got.resize(n, 0);
+    EXPECT(got == exp);
+
+    const std::string tag = scheme == scheme_type::bfv ? "bfv" : "bgv";
+    auto write_ct = [&](const std::string &name, const Ciphertext &ct) {
+        std::ofstream f(dir + "/facade_" + tag + "_" + name + ".bin", std::ios::binary);
+        ct.save(f);
+    };
+    write_ct("c1", c1);
+    write_ct("c2", c2);
+    write_ct("prod", prod);
+    std::ofstream f(dir + "/facade_" + tag + "_dec.bin", std::ios::binary);
+    f.write(reinterpret_cast<const char *>(got.data()), (std::streamsize)(got.size() * 8));
+}
+
 int main(int argc, char **argv)
 {
     try
@@ -758,7 +843,11 @@ int main(int argc, char **argv)
         test_crypto(scheme_type::bfv);
         test_crypto(scheme_type::bgv);
         if (argc > 1)
+        {
             test_serialization(argv[1]);
+            test_plain_modes(argv[1], scheme_type::bfv);
+            test_plain_modes(argv[1], scheme_type::bgv);
+        }
     }
     catch (const std::exception &e)
     {

@@ -58,6 +58,55 @@ def test_cpp_facade_wire_format_matches_oracle(tmp_path, oracle):
         got = (tmp_path / f"facade_{name}.bin").read_bytes()
         assert got == data, f"{name}: {len(got)} bytes written, {len(data)} expected"
 
+    # BFV / BGV with plaintexts: the facade's fresh ciphertexts equal the oracle's (C oracle for the
+    # encryption of zero, oracle/seal_plain.py for the plaintext part), and the oracle decrypts the facade's switched
+    # product to the plaintext the facade decrypted
+    from oracle import seal_plain as sp
+
+    t = 65537
+    primes = oracle.coeff_modulus_create(n, [40, 40, 40, 41])
+    seed = [301, 302, 303, 304, 305, 306, 307, 308]
+    gamma = oracle.get_primes(2 * n, 61, 2)[1]
+    m1 = [(i * i * 7 + 3 * i + 11) % t for i in range(n)]
+    m2 = [(i * 5 + (i % 7) * 1000 + 65000) % t for i in range(n // 2)]
+    for tag, scheme in (("bfv", oracle.SCHEME_BFV), ("bgv", oracle.SCHEME_BGV)):
+        bfv = tag == "bfv"
+        octx = oracle.Context(log_n, primes, scheme, t)
+        p = ser.Params(scheme, n, primes, t)
+        q = primes[:L]
+        sk = octx.seal_secret_key(seed)
+        pk = octx.seal_public_key(sk, seed)
+
+        def fresh(m, use_pk):
+            z = octx.seal_encrypt_zero(L, seed, pk=pk if use_pk else None, sk=sk)
+            m = list(m) + [0] * (n - len(m))  # absent coefficients are zero
+            add = sp.bfv_scale_plain(m, q, t) if bfv else sp.bgv_lift_plain(m, q, t)
+            if not bfv:
+                add = np.stack([oracle.NTTTables(log_n, q[i]).forward(add[i]) for i in range(L)])
+            for i in range(L):
+                z[0, i] = (z[0, i].astype(object) + add[i].astype(object)) % q[i]
+            return z.astype(np.uint64)
+
+        c1, _ = ser.load_ciphertext(p, (tmp_path / f"facade_{tag}_c1.bin").read_bytes())
+        c2, _ = ser.load_ciphertext(p, (tmp_path / f"facade_{tag}_c2.bin").read_bytes())
+        assert (c1["data"] == fresh(m1, False)).all() and (c2["data"] == fresh(m2, True)).all(), tag
+        assert c1["ntt_form"] == (not bfv)
+        prod, _ = ser.load_ciphertext(p, (tmp_path / f"facade_{tag}_prod.bin").read_bytes())
+        assert prod["L"] == L - 1
+        rk = octx.seal_relin_key(sk, seed)
+        mul = octx.bfv_multiply if bfv else octx.ckks_multiply
+        exp_ct = octx.rescale(octx.relinearize(mul(c1["data"], c2["data"]), rk))
+        assert (prod["data"] == exp_ct).all(), tag
+        ph = octx.seal_dot_product(sk, prod["data"], not bfv)
+        if bfv:
+            dec = sp.bfv_decrypt_scale_and_round(ph, q[:-1], t, gamma)
+        else:
+            ph = np.stack([oracle.NTTTables(log_n, q[i]).inverse(ph[i]) for i in range(L - 1)])
+            assert prod["correction_factor"] == pow(q[-1], -1, t)
+            dec = sp.bgv_decrypt_modt(ph, q[:-1], t, prod["correction_factor"])
+        got = np.frombuffer((tmp_path / f"facade_{tag}_dec.bin").read_bytes(), dtype=np.uint64)
+        assert got.tolist() == dec, tag
+
 
 def test_cpp_facade_is_built_and_links_only_the_c_abi():
     """CPU check: the binary exists after build() and the facade header includes nothing from HIP/torch."""
