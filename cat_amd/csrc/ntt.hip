@@ -231,9 +231,20 @@ namespace
             x[e] = in1.p[index(e)];
             y[e] = in2.p[index(e)];
         }
+        // both sources are canonical here (full inverse transforms), so (v + Q/2) mod Q is one conditional subtraction,
+        // and so is the reduction modulo q when Q < 2q (wave-uniform choices)
+        const u64 q = in1.q, nq = 0 - q;
+        const bool close1 = in1.Q < (q << 1), close2 = in2.Q < (q << 1);
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-            x[e] = mul_shoup(in1.derive(x[e]), inv.op, inv.quo, in1.q) + in2.derive(y[e]);
+        {
+            u64 a = guard(x[e] + in1.half, in1.Q, 0 - in1.Q), b = guard(y[e] + in2.half, in2.Q, 0 - in2.Q);
+            if (in1.reduce2)
+                a = close1 ? guard(a, q, nq) : barrett64(a, q, in1.ratio1);
+            if (in2.reduce2)
+                b = close2 ? guard(b, q, nq) : barrett64(b, q, in2.ratio1);
+            x[e] = mul_shoup(a + in1.fix, inv.op, inv.quo, q) + (b + in2.fix);
+        }
     }
 
     // ---- arithmetic policies ----------------------------------------------------------------------------

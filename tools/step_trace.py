@@ -9,7 +9,7 @@ idx = [i for i, n in enumerate(names) if "ckks_tensor_kernel" in n]
 a = idx[-1]
 end = len(rows)
 for i in range(a + 1, len(rows)):
-    if "ntt" not in names[i] and "ks_" not in names[i] and "gather" not in names[i] and "copy" not in names[i].lower():
+    if "ntt" not in names[i] and "ks_" not in names[i] and "gather" not in names[i] and "tail_" not in names[i] and "copy" not in names[i].lower():
         end = i
         break
 t0 = int(rows[a]["Start_Timestamp"])
