@@ -87,6 +87,21 @@ def test_config4_rotate_rescale_chain_n65536_L24(cat, oracle):
         h = host(cur)
         assert (h[2] == h[0]).all() and not (h[1] == h[0]).all()
         L -= 1
+    # the one-call forms at full size (N = 2^16, the level reached above): rotate + rescale and relinearize + rescale
+    # give the words of their two calls for every ciphertext of the batch
+    import torch
+
+    two = ctx.rescale(ctx.rotate_vector(cur.clone(), 1, dgk))
+    one = ctx.apply_galois_rescale(cur.clone(), elt, dgk)
+    assert torch.equal(one, two)
+    rk = dev(octx.relin_key(sk, 45))
+    ct3 = dev(np.stack([octx.uniform(L, 3, 46 + b) for b in range(3)]))
+    seq = ct3.clone()
+    ctx.relinearize(seq, rk)
+    two = torch.empty((3, 2, L - 1, n), dtype=torch.int64, device=ct3.device)
+    ctx.rescale_strided(seq, 2, two)
+    one = ctx.relinearize_rescale(ct3, rk)
+    assert torch.equal(one, two)
     ctx.close()
 
 
