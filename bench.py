@@ -287,7 +287,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel": "batched forward NTT = ntt_fwd_cols<Wide,8> + ntt_fwd_rows8<true> (two launches per transform; `achieved` counts the transform's algorithmic bytes once over the pair's time)",
+            "kernel": "batched forward NTT = ntt_fwd_cols<Wide,8,false> + ntt_fwd_rows8<true> (two launches per transform; `achieved` counts the transform's algorithmic bytes once over the pair's time)",
             "workload": f"N=65536, {args.ntt_limbs} x 60-bit primes, {P} polys ({coeffs * 8 / 1e9:.2f} GB), in place",
             "algorithmic_bytes_per_launch_pair": alg_bytes,
             "forward_ms": f_ms,
