@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the BASELINE.json configurations that are not bench.py's headline line (configs 3, 4, 5), one GPU,
 inputs resident in HBM, each result first checked against the CPU oracle on one batch element.
-Usage: python3 tools/bench_configs.py [--steps K]   -> one JSON object per line."""
+Usage: python3 tests/bench_configs.py [--steps K]   -> one JSON object per line."""
 import argparse
 import json
 import os

@@ -61,8 +61,9 @@ def test_ctx_create_rejects_bad_parameters_without_touching_a_gpu():
 
 
 def test_product_package_does_not_import_the_oracle():
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "cat_amd")):
-        for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".cuh", ".h")):
-                src = open(os.path.join(dirpath, f)).read()
-                assert "seal_oracle" not in src and "oracle/" not in src.replace("oracle/).", ""), f
+    for top in ("cat_amd", "tools", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".cuh", ".h", ".sh")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert "seal_oracle" not in src and "oracle/" not in src.replace("oracle/).", ""), f
