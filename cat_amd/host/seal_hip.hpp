@@ -1039,6 +1039,65 @@ namespace seal
             encrypted = std::move(dest);
         }
 
+        // Not in the reference: relinearize_inplace directly followed by rescale_to_next_inplace (CKKS) or
+        // mod_switch_to_next_inplace (BFV, BGV) -- the usual tail of a multiplication -- as one device call
+        // (cat_relinearize_rescale: one forward transform per limb serves both steps).  Same words, same metadata
+        // and same exceptions as the two calls; sizes other than 3 take the two calls.
+        void relinearize_rescale_inplace(Ciphertext &encrypted, const RelinKeys &relin_keys) const
+        {
+            verify(encrypted, "encrypted");
+            const scheme_type scheme = context_.parms().scheme();
+            auto second = [&] {
+                if (scheme == scheme_type::ckks)
+                    rescale_to_next_inplace(encrypted);
+                else
+                    mod_switch_to_next_inplace(encrypted);
+            };
+            if (encrypted.size() != 3)
+            {
+                relinearize_inplace(encrypted, relin_keys);
+                second();
+                return;
+            }
+            if (relin_keys.size() < 1)
+                throw std::invalid_argument("not enough relinearization keys");
+            const std::uint32_t L = (std::uint32_t)encrypted.coeff_modulus_size();
+            if (L < 2)
+                throw std::invalid_argument("end of modulus switching chain reached");
+            if (scheme == scheme_type::bfv ? encrypted.is_ntt_form() : !encrypted.is_ntt_form())
+                throw std::invalid_argument(scheme == scheme_type::bfv    ? "BFV encrypted cannot be in NTT form"
+                                            : scheme == scheme_type::bgv ? "BGV encrypted must be in NTT form"
+                                                                         : "CKKS encrypted must be in NTT form");
+            Ciphertext dest(context_, L - 1, 2);
+            detail::check(cat_relinearize_rescale(h(), encrypted.d_data(), relin_keys.d_key(RelinKeys::get_index(2)),
+                                                  dest.d_data(), L, 1, nullptr));
+            scaled_metadata(encrypted, dest, L);
+            encrypted = std::move(dest);
+        }
+
+        // Not in the reference: rotate_vector_inplace directly followed by rescale_to_next_inplace (CKKS) as one
+        // device call when the step has its own key (cat_apply_galois_rescale); otherwise the two calls.
+        void rotate_vector_rescale_inplace(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys) const
+        {
+            if (context_.parms().scheme() != scheme_type::ckks)
+                throw std::logic_error("unsupported scheme");
+            verify(encrypted, "encrypted");
+            const std::uint32_t elt = steps ? cat_galois_elt_from_step(log_n(), steps) : 0;
+            const std::uint32_t L = (std::uint32_t)encrypted.coeff_modulus_size();
+            if (!elt || !galois_keys.has_key(elt) || encrypted.size() != 2 || L < 2 || !encrypted.is_ntt_form() ||
+                !context_.using_keyswitching())
+            {
+                rotate_internal(encrypted, steps, galois_keys);
+                rescale_to_next_inplace(encrypted);
+                return;
+            }
+            Ciphertext dest(context_, L - 1, 2);
+            detail::check(cat_apply_galois_rescale(h(), encrypted.d_data(), elt, galois_keys.d_key(GaloisKeys::get_index(elt)),
+                                                   dest.d_data(), L, 1, nullptr));
+            scaled_metadata(encrypted, dest, L);
+            encrypted = std::move(dest);
+        }
+
         // evaluator.cpp:1384-1419: BFV and BGV -> mod_switch_scale_to_next, CKKS -> mod_switch_drop_to_next
         void mod_switch_to_next_inplace(Ciphertext &encrypted) const
         {
@@ -1315,12 +1374,20 @@ namespace seal
             const std::uint32_t L = (std::uint32_t)encrypted.coeff_modulus_size();
             Ciphertext dest(context_, L - 1, encrypted.size());
             detail::check(cat_rescale(h(), encrypted.d_data(), dest.d_data(), L, (std::uint32_t)encrypted.size(), 1, nullptr));
+            scaled_metadata(encrypted, dest, L);
+            destination = std::move(dest);
+        }
+        // what mod_switch_scale_to_next leaves in the destination's header (evaluator.cpp:1256-1279)
+        void scaled_metadata(const Ciphertext &encrypted, Ciphertext &dest, std::uint32_t L) const
+        {
             dest.is_ntt_form() = encrypted.is_ntt_form();
+            dest.scale() = encrypted.scale();
             if (context_.parms().scheme() == scheme_type::ckks)
                 dest.scale() = encrypted.scale() / (double)cat_ctx_modulus(h(), L - 1);
             else if (context_.parms().scheme() == scheme_type::bgv) // :1274-1279
                 dest.correction_factor() = mul_mod_t(encrypted.correction_factor(), cat_bgv_inv_q_last_mod_t(h(), L));
-            destination = std::move(dest);
+            else
+                dest.correction_factor() = encrypted.correction_factor();
         }
         void rotate_internal(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys) const
         {

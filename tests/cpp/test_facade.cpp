@@ -170,6 +170,7 @@ static void test_ckks()
     evaluator.multiply_inplace(encrypted1, encrypted2);
     EXPECT(encrypted1.size() == 3 && encrypted1.is_ntt_form() && encrypted1.scale() == delta * delta);
     EXPECT(encrypted1.to_cpu() == exp3);
+    const Ciphertext encrypted1_size3(encrypted1);
 
     so_relinearize(oc, L, exp3.data(), rk.data());
     evaluator.relinearize_inplace(encrypted1, relin_keys);
@@ -183,6 +184,26 @@ static void test_ckks()
     evaluator.rescale_to_next(encrypted1, rescaled);
     EXPECT(rescaled.coeff_modulus_size() == L - 1 && rescaled.to_cpu() == expr);
     EXPECT(rescaled.scale() == delta * delta / (double)primes[L - 1]);
+
+    // the one-call forms (not in the reference): the words and metadata of the two calls they stand for
+    {
+        Ciphertext a(encrypted1_size3), b(encrypted1_size3);
+        evaluator.relinearize_inplace(a, relin_keys);
+        evaluator.rescale_to_next_inplace(a);
+        evaluator.relinearize_rescale_inplace(b, relin_keys);
+        EXPECT(b.size() == 2 && b.coeff_modulus_size() == L - 1 && b.is_ntt_form() && b.scale() == a.scale());
+        EXPECT(b.to_cpu() == a.to_cpu() && b.to_cpu() == expr);
+        Ciphertext c(encrypted2), d(encrypted2);
+        evaluator.rotate_vector_inplace(c, 1, galois_keys);
+        evaluator.rescale_to_next_inplace(c);
+        evaluator.rotate_vector_rescale_inplace(d, 1, galois_keys);
+        EXPECT(d.coeff_modulus_size() == L - 1 && d.scale() == c.scale() && d.to_cpu() == c.to_cpu());
+        Ciphertext two(encrypted2), two_ref(encrypted2); // size 2: relinearize is a no-op, then the rescale
+        evaluator.rescale_to_next_inplace(two_ref);
+        evaluator.relinearize_rescale_inplace(two, relin_keys);
+        EXPECT(two.to_cpu() == two_ref.to_cpu() && two.scale() == two_ref.scale());
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.rotate_vector_rescale_inplace(d, 3, galois_keys); }));
+    }
 
     // rotate_vector / complex_conjugate (tests/evaluator.cpp:4147, disabled in the reference build)
     {
@@ -272,6 +293,7 @@ static void test_bfv()
     so_bfv_multiply(oc, L, exp3.data(), y.data());
     evaluator.multiply_inplace(encrypted1, encrypted2);
     EXPECT(encrypted1.size() == 3 && encrypted1.to_cpu() == exp3);
+    Ciphertext one_call(encrypted1);
     so_relinearize(oc, L, exp3.data(), rk.data());
     evaluator.relinearize_inplace(encrypted1, relin_keys);
     vec exp2(exp3.begin(), exp3.begin() + 2 * L * n);
@@ -281,6 +303,8 @@ static void test_bfv()
     so_mod_switch_scale_to_next(oc, L, exp2.data(), 2, e.data());
     evaluator.mod_switch_to_next_inplace(encrypted1);
     EXPECT(encrypted1.to_cpu() == e);
+    evaluator.relinearize_rescale_inplace(one_call, relin_keys); // the same two steps as one call
+    EXPECT(one_call.coeff_modulus_size() == L - 1 && !one_call.is_ntt_form() && one_call.to_cpu() == e);
     EXPECT(throws<std::invalid_argument>([&] { evaluator.rescale_to_next_inplace(encrypted2); }));
     so_context_destroy(oc);
 }
@@ -329,6 +353,7 @@ static void test_bgv()
     so_ckks_multiply(oc, L, exp3.data(), y.data()); // the same tensor product (evaluator.cpp:770-798)
     evaluator.multiply_inplace(encrypted1, encrypted2);
     EXPECT(encrypted1.size() == 3 && encrypted1.to_cpu() == exp3 && encrypted1.correction_factor() == 15);
+    Ciphertext one_call(encrypted1);
     so_relinearize(oc, L, exp3.data(), rk.data());
     evaluator.relinearize_inplace(encrypted1, relin_keys);
     vec exp2(exp3.begin(), exp3.begin() + 2 * L * n);
@@ -342,6 +367,9 @@ static void test_bgv()
     EXPECT(encrypted1.coeff_modulus_size() == L - 1 && encrypted1.is_ntt_form() && encrypted1.to_cpu() == e);
     EXPECT(encrypted1.correction_factor() == 15 * inv % t);
     EXPECT(throws<std::invalid_argument>([&] { evaluator.rescale_to_next_inplace(encrypted2); }));
+    evaluator.relinearize_rescale_inplace(one_call, relin_keys); // the same two steps as one call
+    EXPECT(one_call.coeff_modulus_size() == L - 1 && one_call.is_ntt_form() && one_call.to_cpu() == e);
+    EXPECT(one_call.correction_factor() == encrypted1.correction_factor() && one_call.scale() == encrypted1.scale());
 
     // add / sub of operands with different correction factors and sizes (evaluator.cpp:196-237, 302-350)
     for (int sub = 0; sub < 2; ++sub)
