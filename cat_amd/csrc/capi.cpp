@@ -660,10 +660,10 @@ cat_status cat_relinearize_rescale(cat_ctx *ctx, uint64_t *ct3, const uint64_t *
     const u64 *in_end = (const u64 *)ct3 + (size_t)batch * stride, *out_end = (const u64 *)out + (size_t)batch * out_stride;
     if (!(out_end <= (const u64 *)ct3 || in_end <= (const u64 *)out))
         return fail(CAT_ERR_INVALID_ARG, "destination must not alias the inputs");
-    if (ctx->scheme == CAT_SCHEME_CKKS && ctx->log_n >= 12)
+    if ((ctx->scheme == CAT_SCHEME_CKKS || ctx->scheme == CAT_SCHEME_BGV) && ctx->log_n >= 12)
         return launch_switch_key(ctx, (u64 *)ct3, (const u64 *)ct3 + (size_t)2 * L * N, (const u64 *)key, L, batch, stride,
                                  stride, (hipStream_t)s, (u64 *)out, out_stride);
-    // other schemes and small degrees: the two steps one after the other
+    // BFV and small degrees: the two steps one after the other
     st = launch_switch_key(ctx, (u64 *)ct3, (const u64 *)ct3 + (size_t)2 * L * N, (const u64 *)key, L, batch, stride, stride,
                            (hipStream_t)s);
     if (st != CAT_OK)
@@ -847,7 +847,7 @@ static cat_status galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, const
         return st;
     if (!rescale_out)
         return launch_switch_key(ctx, (u64 *)ct, tgt, (const u64 *)key, L, batch, ctw, ctw, (hipStream_t)s);
-    if (ctx->scheme == CAT_SCHEME_CKKS && ctx->log_n >= 12)
+    if ((ctx->scheme == CAT_SCHEME_CKKS || ctx->scheme == CAT_SCHEME_BGV) && ctx->log_n >= 12)
         return launch_switch_key(ctx, (u64 *)ct, tgt, (const u64 *)key, L, batch, ctw, ctw, (hipStream_t)s,
                                  (u64 *)rescale_out, (size_t)2 * (L - 1) * N);
     st = launch_switch_key(ctx, (u64 *)ct, tgt, (const u64 *)key, L, batch, ctw, ctw, (hipStream_t)s);

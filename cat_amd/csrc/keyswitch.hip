@@ -393,6 +393,7 @@ namespace
         const DevMod *mods;
         const MulOp *inv_mod;
         const u64 *half_mod;
+        const MulOp *q_mod; // [k][k]: q_a mod q_b as a multiply operand (BGV)
         u32 d, k, log_n;
         u64 enc_stride2;
         u64 total2; // batch*2*N/2
@@ -451,6 +452,52 @@ namespace
             r.x = sub_mod(u.x, mul_shoup(v.x + fix, pinv.op, pinv.quo, m.q), m.q);
             r.y = sub_mod(u.y, mul_shoup(v.y + fix, pinv.op, pinv.quo, m.q), m.q);
             o[n2] = r;
+        }
+    }
+
+    // BGV form of tail_last_kernel: the mod-down correction of the last limb is delta_{d-1}(buf[p][0]) (bgv_delta)
+    __global__ __launch_bounds__(256) void tail_last_bgv_kernel(TailArgs g, BgvArgs ptP)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1);
+        const DevMod m = g.mods[g.d - 1];
+        const MulOp Pm = g.q_mod[(g.k - 1) * g.k + (g.d - 1)];
+        const MulOp pinv = g.inv_mod[(g.k - 1) * g.k + (g.d - 1)];
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < g.total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 p = i >> (g.log_n - 1);
+            ulonglong2 *o = reinterpret_cast<ulonglong2 *>(g.buf) + ((p * 2) << (g.log_n - 1)) + c;
+            const ulonglong2 v = o[0], u = o[n2];
+            ulonglong2 r;
+            r.x = sub_mod(u.x, mul_shoup(bgv_delta(v.x, ptP, m, Pm), pinv.op, pinv.quo, m.q), m.q);
+            r.y = sub_mod(u.y, mul_shoup(bgv_delta(v.y, ptP, m, Pm), pinv.op, pinv.quo, m.q), m.q);
+            o[n2] = r;
+        }
+    }
+
+    // BGV: tmp[p][j] = delta1_j P^-1 + delta2_j (mod q_j, canonical), j < d-1: delta1 from buf[p][0] (the special-prime
+    // product, divided out by the mod-down), delta2 from buf[p][1] (the relinearized last limb, divided out by the
+    // mod switch); one forward transform of this sum serves both corrections
+    __global__ __launch_bounds__(256) void tail_delta_bgv_kernel(TailArgs g, BgvArgs ptP, BgvArgs ptL, u64 *tmp, u64 total2)
+    {
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        const u32 n2 = 1u << (g.log_n - 1), dl = g.d - 1;
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += stride)
+        {
+            const u32 c = (u32)(i & (n2 - 1));
+            const u64 r = i >> (g.log_n - 1);
+            const u32 j = (u32)(r % dl);
+            const u64 p = r / dl;
+            const DevMod m = g.mods[j];
+            const MulOp Pm = g.q_mod[(g.k - 1) * g.k + j], Lm = g.q_mod[dl * g.k + j];
+            const MulOp pinv = g.inv_mod[(g.k - 1) * g.k + j];
+            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(g.buf) + ((p * 2) << (g.log_n - 1)) + c;
+            const ulonglong2 v = b[0], l = b[n2];
+            ulonglong2 o;
+            o.x = add_mod(mul_shoup(bgv_delta(v.x, ptP, m, Pm), pinv.op, pinv.quo, m.q), bgv_delta(l.x, ptL, m, Lm), m.q);
+            o.y = add_mod(mul_shoup(bgv_delta(v.y, ptP, m, Pm), pinv.op, pinv.quo, m.q), bgv_delta(l.y, ptL, m, Lm), m.q);
+            reinterpret_cast<ulonglong2 *>(tmp)[i] = o;
         }
     }
 
@@ -631,7 +678,7 @@ namespace cat
         if (!ws)
             return CAT_ERR_NOMEM;
         u64 *t_target = ws, *ext = t_target + w_target, *prod = ext + w_ext, *tmp = prod + w_prod, *last = tmp + w_tmp;
-        if (rescale_out && (ctx->scheme != CAT_SCHEME_CKKS || log_n < 12 || d < 2))
+        if (rescale_out && (!ckks || log_n < 12 || d < 2))
             return fail(CAT_ERR_LOGIC, "unsupported fused transform");
         const LimbMap ident = ctx->identity_map();
 
@@ -749,7 +796,7 @@ namespace cat
             g.lazy_shift = ckks ? 2 : 1;
             g.enc_stride2 = enc_stride / 2;
             g.total2 = w_tmp / 2;
-            if (bgv)
+            if (bgv && !rescale_out)
             {
                 // delta (canonical) by its own kernel, then its forward transform; the subtraction, the product with
                 // P^-1 and the accumulation (:2749-2756) are the same finish step as CKKS, on a lazy transform
@@ -795,6 +842,7 @@ namespace cat
                 ta.mods = ctx->d_mods;
                 ta.inv_mod = ctx->d_inv_mod;
                 ta.half_mod = ctx->d_half_mod;
+                ta.q_mod = ctx->d_q_mod;
                 ta.d = d;
                 ta.k = k;
                 ta.log_n = log_n;
@@ -808,17 +856,34 @@ namespace cat
                 st = launch_ntt(ctx, false, last, m2, 2, batch * 2, false, s);
                 if (st != CAT_OK)
                     return st;
-                hipLaunchKernelGGL(tail_last_kernel, dim3(grid_for(ta.total2)), dim3(256), 0, s, ta);
-                CAT_HIP(hipGetLastError());
-                // (c) the remaining d-1 limbs: dual source, two-term epilogue
                 NttFuse g2;
-                g2.src = last;
-                g2.src_stride = (u64)2 * N;
-                g2.src_kind = 1;
-                g2.src_qidx = k - 1;
-                g2.src2 = last + N;
-                g2.src2_stride = (u64)2 * N;
-                g2.src2_qidx = d - 1;
+                if (bgv)
+                {
+                    // the same identities with the BGV corrections (bgv_delta; evaluator.cpp:2715-2758,
+                    // util/rns.cpp:1203-1246): r1_j = delta_j of the special-prime product, r2_j = delta_j of the
+                    // relinearized last limb.  Their sum is written out by its own kernel (the mod-t step does not fit
+                    // the round source), the forward transform keeps the two-term epilogue.
+                    const BgvArgs ptP = bgv_args(ctx, k - 1), ptL = bgv_args(ctx, d - 1);
+                    hipLaunchKernelGGL(tail_last_bgv_kernel, dim3(grid_for(ta.total2)), dim3(256), 0, s, ta, ptP);
+                    CAT_HIP(hipGetLastError());
+                    const u64 total2 = (u64)batch * 2 * (d - 1) * N / 2;
+                    hipLaunchKernelGGL(tail_delta_bgv_kernel, dim3(grid_for(total2)), dim3(256), 0, s, ta, ptP, ptL, tmp,
+                                       total2);
+                    CAT_HIP(hipGetLastError());
+                }
+                else
+                {
+                    hipLaunchKernelGGL(tail_last_kernel, dim3(grid_for(ta.total2)), dim3(256), 0, s, ta);
+                    CAT_HIP(hipGetLastError());
+                    // (c) the remaining d-1 limbs: dual source, two-term epilogue
+                    g2.src = last;
+                    g2.src_stride = (u64)2 * N;
+                    g2.src_kind = 1;
+                    g2.src_qidx = k - 1;
+                    g2.src2 = last + N;
+                    g2.src2_stride = (u64)2 * N;
+                    g2.src2_qidx = d - 1;
+                }
                 g2.ep_other = enc;
                 g2.ep_other_b = enc_stride;
                 g2.ep_other_s = (u64)d * N;

@@ -1190,8 +1190,10 @@ namespace cat
             a.ep_qidx = fuse->ep_qidx;
             // the dual form: a second round source and the two-term epilogue come together, on a forward transform
             // whose first source is a round source
-            if ((fuse->src2 != nullptr) != (fuse->ep_other2 != nullptr) ||
-                (fuse->src2 && (!forward || fuse->src_kind != 1 || !fuse->src || !fuse->ep_dest || fuse->ep_acc || exact)))
+            // (the two-term epilogue also runs alone, over data prepared by the caller: the BGV tail)
+            if ((fuse->src2 && !fuse->ep_other2) ||
+                (fuse->ep_other2 && (!forward || !fuse->ep_dest || fuse->ep_acc || exact)) ||
+                (fuse->src2 && (fuse->src_kind != 1 || !fuse->src)))
                 return fail(CAT_ERR_LOGIC, "unsupported fused transform");
             a.src2 = fuse->src2;
             a.src2_stride = fuse->src2_stride;

@@ -168,7 +168,7 @@ cat_status cat_relinearize(cat_ctx *ctx, uint64_t *d_ct3, const uint64_t *d_key,
 
 /* Evaluator::relinearize_inplace (size 3 -> 2, evaluator.cpp:1144-1199) followed by rescale_to_next / BFV-BGV
  * mod_switch_to_next (:1201-1280, :1481-1519) as one call: d_out (batch x 2 x (L-1) x N, must not overlap d_ct3) receives
- * exactly what the two calls give one after the other.  The reference has no such method; for CKKS at N >= 4096 the
+ * exactly what the two calls give one after the other.  The reference has no such method; for CKKS and BGV at N >= 4096 the
  * mod-down correction and the rescale correction of a limb share one forward transform (the transform is linear and
  * the result canonical, so the words are identical), which removes (L-1) x 2 transforms per ciphertext.  d_ct3
  * (batch x 3 x L x N) is scratch afterwards.  Errors as cat_relinearize and cat_rescale. */
