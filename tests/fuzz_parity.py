@@ -96,6 +96,44 @@ def run_case(cat, so, case, seed):
         y = rand_limbs(rng, sub, (polys,), n, mult=2 if lazy else 1)
         same(ctx.ntt_inverse(dev(y), limb_ids=ids, lazy=lazy), octx.ntt_inverse(y, ids, lazy=lazy), "ntt_inverse")
 
+        # coefficient-wise ops and permutations on the same limb subset
+        import ctypes as C
+
+        lib = so.lib()
+        mods = [so.modulus(q) for q in sub]
+        qv = np.array(sub, dtype=np.uint64)[None, :, None]
+
+        def per_limb(fn, *arrs, scalar=None, elt=None):
+            out = np.zeros_like(arrs[0])
+            for p in range(out.shape[0]):
+                for j in range(len(sub)):
+                    o = np.zeros(n, dtype=np.uint64)
+                    args = [so.ptr(np.ascontiguousarray(v[p, j])) for v in arrs]
+                    if elt is not None:
+                        fn(*args, log_n, elt, *([C.byref(mods[j])] if scalar == "coeff" else []), so.ptr(o))
+                    elif scalar is None:
+                        fn(*args, n, C.byref(mods[j]), so.ptr(o))
+                    else:
+                        fn(*args, n, int(scalar[j]), C.byref(mods[j]), so.ptr(o))
+                    out[p, j] = o
+            return out
+
+        u, v = rand_limbs(rng, sub, (polys,), n), rand_limbs(rng, sub, (polys,), n)
+        du, dv = dev(u), dev(v)
+        same(ctx.add(du, dv, limb_ids=ids), (u + v) % qv, "add")
+        same(ctx.sub(du, dv, limb_ids=ids), (u + (qv - v)) % qv, "sub")
+        same(ctx.negate(du, limb_ids=ids), (qv - u) % qv, "negate")
+        u4 = rand_limbs(rng, sub, (polys,), n, mult=4)
+        same(ctx.dyadic(dev(u4), dv, limb_ids=ids), per_limb(lib.so_dyadic_product_coeffmod, u4, v), "dyadic")
+        sc = [int(rng.integers(0, 1 << 63)) * 2 + 1 for _ in sub]
+        same(ctx.mul_scalar(du, sc, limb_ids=ids), per_limb(lib.so_multiply_poly_scalar_coeffmod, u, scalar=sc),
+             "mul_scalar")
+        gelt = 2 * int(rng.integers(0, n)) + 1
+        same(ctx.apply_galois(du, gelt, limb_ids=ids), per_limb(lib.so_apply_galois, u, scalar="coeff", elt=gelt),
+             f"apply_galois elt={gelt}")
+        same(ctx.apply_galois_ntt(du, gelt), per_limb(lib.so_apply_galois_ntt, u, elt=gelt),
+             f"apply_galois_ntt elt={gelt}")
+
         sk = octx.secret_key(int(rng.integers(1, 1 << 30)))
         rk = octx.relin_key(sk, int(rng.integers(1, 1 << 30)))
         drk = dev(rk)
@@ -116,11 +154,21 @@ def run_case(cat, so, case, seed):
             exp3 = np.stack([octx.ckks_multiply(a[i], b_[i]) for i in range(batch)])
             same(prod, exp3, "ckks_multiply")
             same(ctx.ckks_square(dev(a)), np.stack([octx.ckks_square(a[i]) for i in range(batch)]), "ckks_square")
+            plain = octx.uniform(L, 1, s2 + 50)[0]
+            same(ctx.multiply_plain_ntt(dev(a), dev(plain)),
+                 np.stack([octx.multiply_plain_ntt(a[i], plain) for i in range(batch)]), "multiply_plain_ntt")
+            same(ctx.add_plain(dev(a), dev(plain)), np.stack([octx.add_plain(a[i], plain) for i in range(batch)]),
+                 "add_plain")
+            same(ctx.sub_plain(dev(a), dev(plain)),
+                 np.stack([octx.add_plain(a[i], plain, subtract=True) for i in range(batch)]), "sub_plain")
         exp2 = np.stack([octx.relinearize(exp3[i], rk) for i in range(batch)])
         same(ctx.relinearize(dev(exp3), drk).contiguous(), exp2, "relinearize")
         if L >= 2:
             expr = np.stack([octx.rescale(exp2[i]) for i in range(batch)])
             same(ctx.rescale(dev(exp2)), expr, "rescale / mod switch")
+            buf = dev(exp2)  # in place: the output compacts into the front of the input
+            ctx.rescale(buf, out=buf.view(-1)[: expr.size].view(*expr.shape))
+            same(to_host(buf).reshape(-1)[: expr.size].reshape(expr.shape), expr, "rescale in place")
             same(ctx.relinearize_rescale(dev(exp3), drk), expr, "relinearize_rescale")
             same(ctx.mod_drop(dev(exp2)), np.stack([octx.mod_drop(exp2[i]) for i in range(batch)]), "mod_drop")
         # key switch with an arbitrary target, rotation (with its rescale for the NTT-form schemes)
