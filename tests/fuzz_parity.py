@@ -42,7 +42,9 @@ def draw_case(rng, max_log_n):
         log_n = 14
     log_n = min(log_n, max_log_n)
     k = int(rng.integers(2, 7 if log_n <= 12 else 6))
-    lo = max(log_n + 8, 24)
+    if log_n == 12 and rng.random() < 0.12:
+        k = int(rng.integers(7, 27))  # long chains: the digit loops of key switching (odd and even counts, up to 25 + 1)
+    lo = max(log_n + 8, 24) if k < 7 else 40  # enough primes of each size for a long chain
     style = rng.random()
     if scheme == "ckks" and style < 0.15:
         bits = [61] * k  # SEAL's internal 61-bit primes: the narrow lazy ranges

@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [7001 + i for i in range(10)])
+@pytest.mark.parametrize("seed", [7001 + i for i in range(10)] + [7223, 7255, 7335])  # the last three: long prime chains
 def test_random_case_matches_oracle(oracle, seed):
     import torch
 
