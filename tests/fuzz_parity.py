@@ -39,12 +39,12 @@ def draw_case(rng, max_log_n):
     elif r < 0.95:
         log_n = 13
     else:
-        log_n = 14
+        log_n = int(rng.integers(14, 17))  # 2^14 .. 2^16: every column-pass instantiation
     log_n = min(log_n, max_log_n)
-    k = int(rng.integers(2, 7 if log_n <= 12 else 6))
+    k = int(rng.integers(2, 7 if log_n <= 12 else 6 if log_n <= 14 else 5))
     if log_n == 12 and rng.random() < 0.12:
         k = int(rng.integers(7, 27))  # long chains: the digit loops of key switching (odd and even counts, up to 25 + 1)
-    lo = max(log_n + 8, 24) if k < 7 else 40  # enough primes of each size for a long chain
+    lo = max(log_n + 10, 24) if k < 7 else 40  # enough primes of each size for the chain
     style = rng.random()
     if scheme == "ckks" and style < 0.15:
         bits = [61] * k  # SEAL's internal 61-bit primes: the narrow lazy ranges
@@ -54,6 +54,8 @@ def draw_case(rng, max_log_n):
         bits = [int(rng.integers(lo, 61)) for _ in range(k)]
     t = 0 if scheme == "ckks" else PLAIN_MODULI[int(rng.integers(0, len(PLAIN_MODULI)))]
     batch = int(rng.choice([1, 1, 2, 3, 4, 5, 8, 9]))
+    if log_n >= 15:
+        batch = min(batch, 3)  # keeps the oracle's share of a case to a second or two
     step = int(rng.choice([1, -1, 2, 3, -5, 0]))
     return dict(scheme=scheme, log_n=log_n, bits=bits, t=t, batch=batch, step=step)
 
@@ -196,7 +198,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0 = by time only)")
     ap.add_argument("--seed", type=int, default=20260101)
-    ap.add_argument("--max-log-n", type=int, default=14)
+    ap.add_argument("--max-log-n", type=int, default=16)
     args = ap.parse_args()
 
     import cat_amd as cat
