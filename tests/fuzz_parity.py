@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PLAIN_MODULI = [17, 12289, 65537, 786433, (1 << 20) + 7]
+PLAIN_MODULI = [17, 12289, 65537, 786433, (1 << 20) + 7, 2, 1024]
 
 
 def rand_limbs(rng, primes, prefix, n, mult=1):
@@ -53,6 +53,8 @@ def draw_case(rng, max_log_n):
     else:
         bits = [int(rng.integers(lo, 61)) for _ in range(k)]
     t = 0 if scheme == "ckks" else PLAIN_MODULI[int(rng.integers(0, len(PLAIN_MODULI)))]
+    if scheme == "bgv" and rng.random() < 0.1:
+        t = (1 << 40) + 15  # larger than some primes of the chain: k mod q_i reduces (util/rns.cpp:1228)
     batch = int(rng.choice([1, 1, 2, 3, 4, 5, 8, 9]))
     if log_n >= 15:
         batch = min(batch, 3)  # keeps the oracle's share of a case to a second or two
