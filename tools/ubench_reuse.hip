@@ -54,6 +54,19 @@ __global__ __launch_bounds__(T) void both_passes(u64 *buf)
     for (u32 tile = sub; tile < 16; tile += T / 256) rows_tile(poly, tile, tid);
 }
 
+// the same with P polynomials per workgroup (what sharing one staged twiddle tile between polynomials would need):
+// all column passes first, then all row passes tile group by tile group across the P polynomials
+template <int P>
+__global__ __launch_bounds__(256) void both_passes_multi(u64 *buf)
+{
+    u64 *base = buf + (size_t)blockIdx.x * P * POLY;
+    for (u32 p = 0; p < P; ++p)
+        for (u32 tile = 0; tile < 16; ++tile) cols_tile(base + (size_t)p * POLY, tile, threadIdx.x);
+    __syncthreads();
+    for (u32 tile = 0; tile < 16; ++tile)
+        for (u32 p = 0; p < P; ++p) rows_tile(base + (size_t)p * POLY, tile, threadIdx.x);
+}
+
 int main(int argc, char **argv)
 {
     const size_t polys = argc > 1 ? (size_t)atol(argv[1]) : 16384; // 16384 x 512 KB = 8 GiB
@@ -90,11 +103,14 @@ int main(int argc, char **argv)
     timed("one workgroup per poly, 256 thr", [&] { hipLaunchKernelGGL(both_passes<256>, dim3((u32)polys), dim3(256), 0, 0, buf); });
     timed("one workgroup per poly, 512 thr", [&] { hipLaunchKernelGGL(both_passes<512>, dim3((u32)polys), dim3(512), 0, 0, buf); });
     timed("one workgroup per poly, 1024 thr", [&] { hipLaunchKernelGGL(both_passes<1024>, dim3((u32)polys), dim3(1024), 0, 0, buf); });
-    // every word was incremented 2 x (1 warm-up + 5) x 4 variants times
+    timed("one workgroup per 2 polys, 256 thr", [&] { hipLaunchKernelGGL(both_passes_multi<2>, dim3((u32)(polys / 2)), dim3(256), 0, 0, buf); });
+    timed("one workgroup per 4 polys, 256 thr", [&] { hipLaunchKernelGGL(both_passes_multi<4>, dim3((u32)(polys / 4)), dim3(256), 0, 0, buf); });
+    timed("one workgroup per 8 polys, 256 thr", [&] { hipLaunchKernelGGL(both_passes_multi<8>, dim3((u32)(polys / 8)), dim3(256), 0, 0, buf); });
+    // every word was incremented 2 x (1 warm-up + 5) x 7 variants times
     u64 h[2];
     CK(hipMemcpy(h, buf, 8, hipMemcpyDeviceToHost));
     CK(hipMemcpy(h + 1, buf + polys * POLY - 1, 8, hipMemcpyDeviceToHost));
-    printf("check: first word %llu, last word %llu (expected %d)\n", h[0], h[1], 2 * 6 * 4);
+    printf("check: first word %llu, last word %llu (expected %d)\n", h[0], h[1], 2 * 6 * 7);
     CK(hipFree(buf));
     return 0;
 }
