@@ -507,21 +507,15 @@ namespace
     }
 
     // ---- forward, pass 1: columns ----------------------------------------------------------------------
-    template <class P, int LOGN1, bool DUAL = false>
-    __global__ __launch_bounds__(256) void ntt_fwd_cols(NttArgs a)
+    // one column tile (C columns x N1 rows) of the limb-polynomial w points at; tw = the staged column twiddles
+    template <class P, int LOGN1, bool DUAL>
+    __device__ __forceinline__ void fwd_cols_tile(const NttArgs &a, const Where &w, const typename P::Mod &m,
+                                                  const typename P::Table &tw, u64 *lds)
     {
         constexpr int K1 = LOGN1 - 4;          // stages done in round 1
         constexpr int N1 = 1 << LOGN1;
         constexpr int C = TILE_WORDS / N1;     // columns per workgroup
         constexpr int SUB = 16 >> K1;          // consecutive rows per thread in round 1
-        __shared__ u64 lds[TILE_WORDS];
-
-        const Where w = locate(a, blockIdx.x, ROW_LEN / C);
-        if (w.skip)
-            return;
-        const typename P::Mod m = P::mod(a.mods[w.mod]);
-        __shared__ u64 twl[3 * 256];
-        const typename P::Table tw = stage_col_twiddles(twl, P::table(a.tw, w.mod, a.log_n, false), a.log_n, false);
         u64 *p = a.data + w.offset + w.tile * C;
         const Source in = source(a, w, w.tile * C);
 
@@ -571,17 +565,25 @@ namespace
             p[(tau * 16 + l) * ROW_LEN + c] = x[l];
     }
 
-    // ---- forward, pass 2: rows (16 rows of 256 per workgroup) -------------------------------------------
-    template <class P>
-    __global__ __launch_bounds__(256) void ntt_fwd_rows(NttArgs a)
+    template <class P, int LOGN1, bool DUAL = false>
+    __global__ __launch_bounds__(256) void ntt_fwd_cols(NttArgs a)
     {
-        __shared__ u64 lds[16 * ROW_PITCH];
-        const u32 n1 = 1u << (a.log_n - 8);
-        const Where w = locate(a, blockIdx.x, n1 / 16);
+        __shared__ u64 lds[TILE_WORDS];
+        const Where w = locate(a, blockIdx.x, ROW_LEN / (TILE_WORDS >> LOGN1));
         if (w.skip)
             return;
         const typename P::Mod m = P::mod(a.mods[w.mod]);
-        const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, false);
+        __shared__ u64 twl[3 * 256];
+        const typename P::Table tw = stage_col_twiddles(twl, P::table(a.tw, w.mod, a.log_n, false), a.log_n, false);
+        fwd_cols_tile<P, LOGN1, DUAL>(a, w, m, tw, lds);
+    }
+
+    // ---- forward, pass 2: rows (16 rows of 256 per workgroup) -------------------------------------------
+    template <class P>
+    __device__ __forceinline__ void fwd_rows_tile(const NttArgs &a, const Where &w, const typename P::Mod &m,
+                                                  const typename P::Table &tw, u64 *lds)
+    {
+        const u32 n1 = 1u << (a.log_n - 8);
         const u32 r = threadIdx.x >> 4, t = threadIdx.x & 15;
         const u32 row = w.tile * 16 + r;
         u64 *p = a.data + w.offset + (size_t)row * ROW_LEN;
@@ -650,6 +652,54 @@ namespace
 #pragma unroll
         for (int h = 0; h < 16; ++h)
             p[h * 16 + t] = s[h * 17 + t];
+    }
+
+    template <class P>
+    __global__ __launch_bounds__(256) void ntt_fwd_rows(NttArgs a)
+    {
+        __shared__ u64 lds[16 * ROW_PITCH];
+        const u32 n1 = 1u << (a.log_n - 8);
+        const Where w = locate(a, blockIdx.x, n1 / 16);
+        if (w.skip)
+            return;
+        const typename P::Mod m = P::mod(a.mods[w.mod]);
+        const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, false);
+        fwd_rows_tile<P>(a, w, m, tw, lds);
+    }
+
+    // ---- forward, both passes by one workgroup (experiment, CAT_NTT_FUSED=1; N = 2^16, plain in-place transforms) ----
+    // The workgroup owns one limb-polynomial: 16 column tiles, a barrier, 16 row tiles.  Its second pass finds part of
+    // the polynomial in cache (tools/ubench_reuse.hip: 1.38 x on the memory side); the row twiddles come from L2,
+    // which the limb-slowest workgroup order keeps on one prime at a time.  Measured on MI355X, config 2: 15.9 ms
+    // against 15.6 ms for the two launches (130 VGPRs, 3 waves per SIMD; forced to 4 it spills and takes 16.3 ms):
+    // bit-exact, but the time moved from memory to the instruction stream, so it stays off by default.
+    template <class P>
+    __global__ __launch_bounds__(256) void ntt_fwd_fused16(NttArgs a)
+    {
+        constexpr int LDS_WORDS = TILE_WORDS > 16 * ROW_PITCH ? TILE_WORDS : 16 * ROW_PITCH;
+        __shared__ u64 lds[LDS_WORDS];
+        __shared__ u64 twl[3 * 256];
+        Where w = locate(a, blockIdx.x, 1);
+        if (w.skip)
+            return;
+        const typename P::Mod m = P::mod(a.mods[w.mod]);
+        {
+            const typename P::Table twc = stage_col_twiddles(twl, P::table(a.tw, w.mod, a.log_n, false), a.log_n, false);
+            for (u32 tile = 0; tile < 16; ++tile)
+            {
+                w.tile = tile;
+                fwd_cols_tile<P, 8, false>(a, w, m, twc, lds);
+                __syncthreads(); // the tile's LDS exchange is over before the next tile writes
+            }
+        }
+        // workgroup-scope: every column-pass store of this workgroup is visible to its row pass
+        __syncthreads();
+        const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, false);
+        for (u32 tile = 0; tile < 16; ++tile)
+        {
+            w.tile = tile;
+            fwd_rows_tile<P>(a, w, m, tw, lds);
+        }
     }
 
     // ---- forward, pass 2, poly-streaming form (Fast policy, no fused epilogue) ------------------------------
@@ -1071,6 +1121,13 @@ namespace
             default: launch_cols<P, 8>(forward, a, (u32)col_blocks, s); break;
             }
         };
+        static const bool fused16 = getenv("CAT_NTT_FUSED") != nullptr; // experiment: both passes by one workgroup
+        if (forward && fused16 && logn1 == 8 && !first_only && !a.src && !a.ep_dest && n_lp <= 0x7fffffffu)
+        {
+            hipLaunchKernelGGL((ntt_fwd_fused16<P>), dim3((u32)n_lp), dim3(256), 0, s, a);
+            CAT_HIP(hipGetLastError());
+            return CAT_OK;
+        }
         if (forward)
         {
             cols();
