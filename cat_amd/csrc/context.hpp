@@ -124,7 +124,8 @@ namespace cat
         //   round(src; Q) * Q^-1 + round(src2; Q2)      (Q = prime src_qidx, Q2 = prime src2_qidx)
         // and the epilogue dest = ((other + other2 * Q2e^-1) + 4q - t) * Qe^-1 with Qe = prime ep_qidx,
         // Q2e = prime ep_qidx2.  By linearity of the transform this equals the mod-down finish followed by the
-        // rescale finish modulo q, and the output is canonical.
+        // rescale finish modulo q, and the output is canonical.  The two-term epilogue may also come without src2,
+        // over data the caller prepared itself (the BGV tail writes its two corrections with its own kernel).
         const u64 *src2 = nullptr;
         u64 src2_stride = 0;
         uint32_t src2_qidx = 0;
