@@ -1190,7 +1190,214 @@ namespace seal
             apply_galois_inplace(encrypted, cat_galois_elt_from_step(log_n(), 0), galois_keys);
         }
 
+        // ---- the reference's out-of-place and chained forms (evaluator.h): each is the copy / loop it is there ----
+        void negate(const Ciphertext &encrypted, Ciphertext &destination) const // evaluator.h:111-115
+        {
+            destination = encrypted;
+            negate_inplace(destination);
+        }
+        void add(const Ciphertext &encrypted1, const Ciphertext &encrypted2, Ciphertext &destination) const // :139-150
+        {
+            if (&encrypted2 == &destination)
+                add_inplace(destination, encrypted1);
+            else
+            {
+                destination = encrypted1;
+                add_inplace(destination, encrypted2);
+            }
+        }
+        void add_many(const std::vector<Ciphertext> &encrypteds, Ciphertext &destination) const // evaluator.cpp:242-261
+        {
+            if (encrypteds.empty())
+                throw std::invalid_argument("encrypteds cannot be empty");
+            for (const Ciphertext &c : encrypteds)
+                if (&c == &destination)
+                    throw std::invalid_argument("encrypteds must be different from destination");
+            destination = encrypteds[0];
+            for (std::size_t i = 1; i < encrypteds.size(); ++i)
+                add_inplace(destination, encrypteds[i]);
+        }
+        void sub(const Ciphertext &encrypted1, const Ciphertext &encrypted2, Ciphertext &destination) const // :187-199
+        {
+            if (&encrypted2 == &destination)
+            {
+                sub_inplace(destination, encrypted1);
+                negate_inplace(destination);
+            }
+            else
+            {
+                destination = encrypted1;
+                sub_inplace(destination, encrypted2);
+            }
+        }
+        void square(const Ciphertext &encrypted, Ciphertext &destination) const // :262-267
+        {
+            destination = encrypted;
+            square_inplace(destination);
+        }
+        void relinearize(const Ciphertext &encrypted, const RelinKeys &relin_keys, Ciphertext &destination) const // :327-333
+        {
+            destination = encrypted;
+            relinearize_inplace(destination, relin_keys);
+        }
+        void mod_switch_to_next(const Ciphertext &encrypted, Ciphertext &destination) const // :352-355
+        {
+            destination = encrypted;
+            mod_switch_to_next_inplace(destination);
+        }
+        // evaluator.cpp:1429-1451
+        void mod_switch_to_inplace(Ciphertext &encrypted, const parms_id_type &parms_id) const
+        {
+            check_target_level(encrypted, parms_id);
+            while (encrypted.parms_id() != parms_id)
+                mod_switch_to_next_inplace(encrypted);
+        }
+        void mod_switch_to(const Ciphertext &encrypted, const parms_id_type &parms_id, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            mod_switch_to_inplace(destination, parms_id);
+        }
+        // evaluator.cpp:1521-1570
+        void rescale_to_inplace(Ciphertext &encrypted, const parms_id_type &parms_id) const
+        {
+            verify(encrypted, "encrypted");
+            check_target_level(encrypted, parms_id);
+            if (context_.parms().scheme() != scheme_type::ckks)
+                throw std::invalid_argument("unsupported operation for scheme type");
+            while (encrypted.parms_id() != parms_id)
+                rescale_to_next_inplace(encrypted);
+        }
+        void rescale_to(const Ciphertext &encrypted, const parms_id_type &parms_id, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            rescale_to_inplace(destination, parms_id);
+        }
+        // evaluator.cpp:1627-1702: the pairwise product tree, relinearized after every product (BFV and BGV)
+        void multiply_many(const std::vector<Ciphertext> &encrypteds, const RelinKeys &relin_keys, Ciphertext &destination) const
+        {
+            if (encrypteds.empty())
+                throw std::invalid_argument("encrypteds vector must not be empty");
+            for (const Ciphertext &c : encrypteds)
+                if (&c == &destination)
+                    throw std::invalid_argument("encrypteds must be different from destination");
+            verify(encrypteds[0], "encrypteds");
+            if (context_.parms().scheme() != scheme_type::bfv && context_.parms().scheme() != scheme_type::bgv)
+                throw std::logic_error("unsupported scheme");
+            if (encrypteds.size() == 1)
+            {
+                destination = encrypteds[0];
+                return;
+            }
+            std::vector<Ciphertext> product_vec;
+            for (std::size_t i = 0; i + 1 < encrypteds.size(); i += 2)
+            {
+                Ciphertext temp;
+                if (encrypteds[i].d_data() == encrypteds[i + 1].d_data())
+                    square(encrypteds[i], temp);
+                else
+                    multiply(encrypteds[i], encrypteds[i + 1], temp);
+                relinearize_inplace(temp, relin_keys);
+                product_vec.emplace_back(std::move(temp));
+            }
+            if (encrypteds.size() & 1)
+                product_vec.emplace_back(encrypteds.back());
+            for (std::size_t i = 0; i + 1 < product_vec.size(); i += 2)
+            {
+                Ciphertext temp;
+                multiply(product_vec[i], product_vec[i + 1], temp);
+                relinearize_inplace(temp, relin_keys);
+                product_vec.emplace_back(std::move(temp));
+            }
+            destination = product_vec.back();
+        }
+        // evaluator.cpp:1704-1736
+        void exponentiate_inplace(Ciphertext &encrypted, std::uint64_t exponent, const RelinKeys &relin_keys) const
+        {
+            verify(encrypted, "encrypted");
+            if (exponent == 0)
+                throw std::invalid_argument("exponent cannot be 0");
+            if (exponent == 1)
+                return;
+            std::vector<Ciphertext> exp_vector(static_cast<std::size_t>(exponent), encrypted);
+            multiply_many(exp_vector, relin_keys, encrypted);
+        }
+        void exponentiate(const Ciphertext &encrypted, std::uint64_t exponent, const RelinKeys &relin_keys,
+                          Ciphertext &destination) const
+        {
+            destination = encrypted;
+            exponentiate_inplace(destination, exponent, relin_keys);
+        }
+        void multiply_plain(const Ciphertext &encrypted, const Plaintext &plain, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            multiply_plain_inplace(destination, plain);
+        }
+        void add_plain(const Ciphertext &encrypted, const Plaintext &plain, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            add_plain_inplace(destination, plain);
+        }
+        void sub_plain(const Ciphertext &encrypted, const Plaintext &plain, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            sub_plain_inplace(destination, plain);
+        }
+        void transform_to_ntt(const Ciphertext &encrypted, Ciphertext &destination_ntt) const
+        {
+            destination_ntt = encrypted;
+            transform_to_ntt_inplace(destination_ntt);
+        }
+        void transform_from_ntt(const Ciphertext &encrypted_ntt, Ciphertext &destination) const
+        {
+            destination = encrypted_ntt;
+            transform_from_ntt_inplace(destination);
+        }
+        void apply_galois(const Ciphertext &encrypted, std::uint32_t galois_elt, const GaloisKeys &galois_keys,
+                          Ciphertext &destination) const
+        {
+            destination = encrypted;
+            apply_galois_inplace(destination, galois_elt, galois_keys);
+        }
+        void rotate_vector(const Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            rotate_vector_inplace(destination, steps, galois_keys);
+        }
+        void rotate_rows(const Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            rotate_rows_inplace(destination, steps, galois_keys);
+        }
+        // evaluator.h:1127-1141: the column swap of the batching matrix = Galois element 2N - 1
+        void rotate_columns_inplace(Ciphertext &encrypted, const GaloisKeys &galois_keys) const
+        {
+            if (context_.parms().scheme() != scheme_type::bfv && context_.parms().scheme() != scheme_type::bgv)
+                throw std::logic_error("unsupported scheme");
+            apply_galois_inplace(encrypted, cat_galois_elt_from_step(log_n(), 0), galois_keys);
+        }
+        void rotate_columns(const Ciphertext &encrypted, const GaloisKeys &galois_keys, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            rotate_columns_inplace(destination, galois_keys);
+        }
+        void complex_conjugate(const Ciphertext &encrypted, const GaloisKeys &galois_keys, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            complex_conjugate_inplace(destination, galois_keys);
+        }
+
     private:
+        // mod_switch_to / rescale_to: both levels exist and the target is not above the operand (evaluator.cpp:1432-1446)
+        void check_target_level(const Ciphertext &encrypted, const parms_id_type &parms_id) const
+        {
+            const std::size_t have = context_.level_of(encrypted.parms_id()), want = context_.level_of(parms_id);
+            if (!have)
+                throw std::invalid_argument("encrypted is not valid for encryption parameters");
+            if (!want)
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            if (have < want)
+                throw std::invalid_argument("cannot switch to higher level modulus");
+        }
         cat_ctx *h() const noexcept
         {
             return context_.handle();

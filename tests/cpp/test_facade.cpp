@@ -205,6 +205,61 @@ static void test_ckks()
         EXPECT(throws<std::invalid_argument>([&] { evaluator.rotate_vector_rescale_inplace(d, 3, galois_keys); }));
     }
 
+    // out-of-place and chained forms (evaluator.h): the copies / loops they are in the reference
+    {
+        Ciphertext a, b;
+        evaluator.add(encrypted2, encrypted2, a);
+        b = encrypted2;
+        evaluator.add_inplace(b, encrypted2);
+        EXPECT(a.to_cpu() == b.to_cpu());
+        evaluator.sub(encrypted2, a, a); // destination is the second operand: x - 2x = -x
+        evaluator.negate(encrypted2, b);
+        EXPECT(a.to_cpu() == b.to_cpu());
+        const std::vector<Ciphertext> many{ encrypted2, encrypted2, encrypted2 };
+        evaluator.add_many(many, a);
+        b = encrypted2;
+        evaluator.add_inplace(b, encrypted2);
+        evaluator.add_inplace(b, encrypted2);
+        EXPECT(a.to_cpu() == b.to_cpu());
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.add_many(std::vector<Ciphertext>{}, a); }));
+        // rescale_to / mod_switch_to walk the chain (evaluator.cpp:1429-1451, 1521-1570)
+        Ciphertext c(encrypted2), d(encrypted2);
+        evaluator.rescale_to_next_inplace(c);
+        evaluator.rescale_to_next_inplace(c);
+        evaluator.rescale_to_inplace(d, context.parms_id(L - 2));
+        EXPECT(d.coeff_modulus_size() == L - 2 && d.to_cpu() == c.to_cpu() && d.scale() == c.scale());
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.rescale_to_inplace(d, context.parms_id(L)); })); // higher level
+        Ciphertext m1(encrypted2), m2;
+        evaluator.mod_switch_to_next_inplace(m1);
+        evaluator.mod_switch_to(encrypted2, context.parms_id(L - 1), m2);
+        EXPECT(m2.to_cpu() == m1.to_cpu() && m2.scale() == encrypted2.scale());
+        evaluator.mod_switch_to_inplace(m2, m2.parms_id()); // already there
+        EXPECT(m2.to_cpu() == m1.to_cpu());
+        parms_id_type bogus = context.parms_id(L);
+        bogus[0] ^= 1;
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.mod_switch_to_inplace(m2, bogus); }));
+        Ciphertext sq1(encrypted2), sq2, r1(encrypted2), r2, t1(encrypted2), t2;
+        evaluator.square_inplace(sq1);
+        evaluator.square(encrypted2, sq2);
+        EXPECT(sq1.to_cpu() == sq2.to_cpu() && sq2.size() == 3);
+        evaluator.relinearize(sq2, relin_keys, r2);
+        evaluator.relinearize_inplace(sq1, relin_keys);
+        EXPECT(r2.size() == 2 && r2.to_cpu() == sq1.to_cpu());
+        evaluator.rotate_vector_inplace(r1, 2, galois_keys);
+        evaluator.rotate_vector(encrypted2, 2, galois_keys, r2);
+        EXPECT(r2.to_cpu() == r1.to_cpu());
+        evaluator.complex_conjugate(encrypted2, galois_keys, r2);
+        evaluator.apply_galois(encrypted2, eltc, galois_keys, r1);
+        EXPECT(r2.to_cpu() == r1.to_cpu());
+        evaluator.transform_from_ntt_inplace(t1);
+        evaluator.transform_from_ntt(encrypted2, t2);
+        EXPECT(!t2.is_ntt_form() && t2.to_cpu() == t1.to_cpu());
+        evaluator.transform_to_ntt(t2, t1);
+        EXPECT(t1.is_ntt_form() && t1.to_cpu() == y);
+        EXPECT(throws<std::logic_error>([&] { evaluator.multiply_many(many, relin_keys, a); }));       // CKKS: unsupported scheme
+        EXPECT(throws<std::logic_error>([&] { evaluator.rotate_columns_inplace(r1, galois_keys); })); // BFV / BGV only
+    }
+
     // rotate_vector / complex_conjugate (tests/evaluator.cpp:4147, disabled in the reference build)
     {
         Ciphertext r(encrypted2);
@@ -306,6 +361,32 @@ static void test_bfv()
     evaluator.relinearize_rescale_inplace(one_call, relin_keys); // the same two steps as one call
     EXPECT(one_call.coeff_modulus_size() == L - 1 && !one_call.is_ntt_form() && one_call.to_cpu() == e);
     EXPECT(throws<std::invalid_argument>([&] { evaluator.rescale_to_next_inplace(encrypted2); }));
+
+    // multiply_many / exponentiate (evaluator.cpp:1627-1736): the product tree, relinearized after every product
+    {
+        Ciphertext a(context, L), b(context, L), c(context, L);
+        a.upload(x.data());
+        b.upload(y.data());
+        vec z = uniform(oc, L, 2, n, 22);
+        c.upload(z.data());
+        auto mul_relin = [&](const vec &u, const vec &v) {
+            vec p3(3 * L * n, 0);
+            std::memcpy(p3.data(), u.data(), u.size() * 8);
+            so_bfv_multiply(oc, L, p3.data(), v.data());
+            so_relinearize(oc, L, p3.data(), rk.data());
+            return vec(p3.begin(), p3.begin() + 2 * L * n);
+        };
+        Ciphertext prod3, power;
+        evaluator.multiply_many({ a, b, c }, relin_keys, prod3); // (a b) then ((a b) c)... the tree: [ab, c] -> (ab) c
+        EXPECT(prod3.size() == 2 && prod3.to_cpu() == mul_relin(mul_relin(x, y), z));
+        evaluator.exponentiate(a, 4, relin_keys, power);          // [a a, a a] -> (a a)(a a)
+        const vec a2 = mul_relin(x, x);
+        EXPECT(power.to_cpu() == mul_relin(a2, a2));
+        evaluator.exponentiate_inplace(b, 1, relin_keys);
+        EXPECT(b.to_cpu() == y);
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.exponentiate_inplace(b, 0, relin_keys); }));
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.multiply_many({ a, b }, relin_keys, prod3); evaluator.multiply_many({}, relin_keys, prod3); }));
+    }
     so_context_destroy(oc);
 }
 
