@@ -557,6 +557,11 @@ namespace seal
         {
             return buf_.scale();
         }
+        // plaintext.h: parms_id_zero for a coefficient-form (BFV / BGV) plaintext, the level's id in NTT form
+        parms_id_type parms_id() const
+        {
+            return buf_.d_data() ? buf_.parms_id() : parms_id_zero;
+        }
         // Plaintext::save_members / load_members (plaintext.cpp:207-290) for an NTT-form plaintext: parms_id of its
         // level, coeff_count = limbs x N, scale, data
         std::streamoff save(std::ostream &stream) const
@@ -1244,6 +1249,46 @@ namespace seal
         {
             destination = encrypted;
             mod_switch_to_next_inplace(destination);
+        }
+        // NTT-form plaintexts drop their last limb: mod_switch_drop_to_next(Plaintext &) evaluator.cpp:1347-1382,
+        // mod_switch_to_next_inplace :1421-1427, mod_switch_to_inplace :1453-1479
+        void mod_switch_to_next_inplace(Plaintext &plain) const
+        {
+            if (!plain.d_data() || plain.coeff_modulus_size() == 0)
+                throw std::invalid_argument("plain is not valid for encryption parameters");
+            if (!plain.is_ntt_form())
+                throw std::invalid_argument("plain is not in NTT form");
+            const std::uint32_t L = (std::uint32_t)plain.coeff_modulus_size();
+            if (L < 2)
+                throw std::invalid_argument("end of modulus switching chain reached");
+            Plaintext dest(context_, L - 1);
+            detail::check(cat_mod_drop(h(), plain.d_data(), dest.d_data(), L, 1, 1, nullptr));
+            dest.scale() = plain.scale();
+            plain = std::move(dest);
+        }
+        void mod_switch_to_next(const Plaintext &plain, Plaintext &destination) const
+        {
+            destination = plain;
+            mod_switch_to_next_inplace(destination);
+        }
+        void mod_switch_to_inplace(Plaintext &plain, const parms_id_type &parms_id) const
+        {
+            const std::size_t have = plain.d_data() ? plain.coeff_modulus_size() : 0, want = context_.level_of(parms_id);
+            if (!have)
+                throw std::invalid_argument("plain is not valid for encryption parameters");
+            if (!want)
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            if (!plain.is_ntt_form())
+                throw std::invalid_argument("plain is not in NTT form");
+            if (have < want)
+                throw std::invalid_argument("cannot switch to higher level modulus");
+            while (plain.coeff_modulus_size() != want)
+                mod_switch_to_next_inplace(plain);
+        }
+        void mod_switch_to(const Plaintext &plain, const parms_id_type &parms_id, Plaintext &destination) const
+        {
+            destination = plain;
+            mod_switch_to_inplace(destination, parms_id);
         }
         // evaluator.cpp:1429-1451
         void mod_switch_to_inplace(Ciphertext &encrypted, const parms_id_type &parms_id) const

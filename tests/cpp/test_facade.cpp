@@ -256,6 +256,17 @@ static void test_ckks()
         EXPECT(!t2.is_ntt_form() && t2.to_cpu() == t1.to_cpu());
         evaluator.transform_to_ntt(t2, t1);
         EXPECT(t1.is_ntt_form() && t1.to_cpu() == y);
+        // NTT-form plaintexts drop limbs (evaluator.cpp:1347-1382, 1453-1479)
+        Plaintext pl(context, L), pl2;
+        pl.upload(x.data());
+        pl.scale() = delta;
+        evaluator.mod_switch_to(pl, context.parms_id(L - 2), pl2);
+        EXPECT(pl2.coeff_modulus_size() == L - 2 && pl2.scale() == delta && pl2.parms_id() == context.parms_id(L - 2));
+        EXPECT(pl2.to_cpu() == vec(x.begin(), x.begin() + (L - 2) * n));
+        evaluator.mod_switch_to_next_inplace(pl);
+        EXPECT(pl.to_cpu() == vec(x.begin(), x.begin() + (L - 1) * n));
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.mod_switch_to_next_inplace(pl2); })); // end of chain
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.mod_switch_to_inplace(pl2, context.parms_id(L)); }));
         EXPECT(throws<std::logic_error>([&] { evaluator.multiply_many(many, relin_keys, a); }));       // CKKS: unsupported scheme
         EXPECT(throws<std::logic_error>([&] { evaluator.rotate_columns_inplace(r1, galois_keys); })); // BFV / BGV only
     }
