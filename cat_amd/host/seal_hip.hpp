@@ -1605,11 +1605,17 @@ namespace seal
                 dest.scale() = encrypted1.scale() * encrypted2.scale();
             encrypted1 = std::move(dest);
         }
+        // BFV / BGV branches of add_plain / sub_plain (coefficient-form plaintext modulo t, evaluator.cpp:1737-1951);
+        // defined in seal_hip_crypto.hpp next to the plaintext scaling / lifting it shares with Encryptor
+        void plain_addsub_coeff(Ciphertext &encrypted, const Plaintext &plain, bool sub) const;
         void plain_addsub(Ciphertext &encrypted, const Plaintext &plain, bool sub) const
         {
             verify(encrypted, "encrypted");
             if (context_.parms().scheme() != scheme_type::ckks)
-                throw std::logic_error("unsupported: plaintext add/sub on the device is the CKKS branch only");
+            {
+                plain_addsub_coeff(encrypted, plain, sub);
+                return;
+            }
             if (!encrypted.is_ntt_form() || !plain.is_ntt_form())
                 throw std::invalid_argument("NTT form mismatch");
             if (encrypted.coeff_modulus_size() != plain.coeff_modulus_size())

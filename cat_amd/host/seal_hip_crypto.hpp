@@ -722,6 +722,46 @@ namespace seal
         SecretKey secret_key_;
     };
 
+    // Evaluator::add_plain_inplace / sub_plain_inplace, BFV and BGV (evaluator.cpp:1737-1951).  BFV: c0 +- round(q m / t)
+    // at the ciphertext's level (multiply_add / multiply_sub_plain_with_scaling_variant, util/scalingvariant.cpp:69-165);
+    // BGV: m times the ciphertext's correction factor modulo t, lifted and transformed
+    // (transform_to_ntt_inplace(Plaintext &), evaluator.cpp:2174-2265), added to or subtracted from c0.
+    inline void Evaluator::plain_addsub_coeff(Ciphertext &encrypted, const Plaintext &plain, bool sub) const
+    {
+        const scheme_type scheme = context_.parms().scheme();
+        const bool bfv = scheme == scheme_type::bfv;
+        if (!bfv && scheme != scheme_type::bgv)
+            throw std::invalid_argument("unsupported scheme");
+        if (bfv ? encrypted.is_ntt_form() : !encrypted.is_ntt_form())
+            throw std::invalid_argument(bfv ? "BFV encrypted cannot be in NTT form" : "BGV encrypted must be in NTT form");
+        if (plain.is_ntt_form())
+            throw std::invalid_argument(bfv ? "BFV plain cannot be in NTT form" : "BGV plain cannot be in NTT form");
+        const std::size_t L = encrypted.coeff_modulus_size(), n = context_.poly_modulus_degree();
+        const std::uint64_t t = context_.parms().plain_modulus();
+        if (plain.coeff_count() > n)
+            throw std::invalid_argument("plain is not valid for encryption parameters");
+        for (std::uint64_t c : plain.data())
+            if (c >= t)
+                throw std::invalid_argument("plain is not valid for encryption parameters");
+        const detail::PlainTools tools(detail::level_primes(context_, L), t, 0);
+        std::vector<std::uint64_t> add(L * n);
+        if (bfv)
+            tools.scale_plain(plain.data(), n, add.data());
+        else
+        {
+            std::vector<std::uint64_t> scaled(plain.data());
+            for (std::uint64_t &c : scaled)
+                c = mul_mod_t(c, encrypted.correction_factor());
+            tools.lift_plain(scaled, n, add.data());
+        }
+        detail::DeviceWords d_add(context_.handle(), add);
+        if (!bfv)
+            detail::check(cat_ntt_forward(context_.handle(), d_add.get(), nullptr, (std::uint32_t)L, 1, 0, nullptr));
+        detail::check((sub ? cat_sub : cat_add)(context_.handle(), encrypted.d_data(0), d_add.get(), encrypted.d_data(0), nullptr,
+                                                (std::uint32_t)L, 1, nullptr));
+        detail::check(cat_stream_sync(context_.handle(), nullptr));
+    }
+
     class Decryptor
     {
     public:

@@ -939,6 +939,44 @@ static void test_plain_modes(const std::string &dir, scheme_type scheme)
     got.resize(n, 0);
     EXPECT(got == exp);
 
+    // add_plain / sub_plain with a coefficient-form plaintext (evaluator.cpp:1737-1951), fresh and after the mod switch
+    // (BGV: the correction factor of the switched ciphertext scales the plaintext)
+    {
+        vec sum(n), diff(n);
+        for (size_t i = 0; i < n; ++i)
+        {
+            const uint64_t b = i < m2.size() ? m2[i] : 0;
+            sum[i] = (m1[i] + b) % t;
+            diff[i] = (m1[i] + t - b) % t;
+        }
+        auto dec = [&](const Ciphertext &ct) {
+            Plaintext p;
+            decryptor.decrypt(ct, p);
+            vec v = p.data();
+            v.resize(n, 0);
+            return v;
+        };
+        Ciphertext a(c1), s2;
+        evaluator.add_plain_inplace(a, Plaintext(m2));
+        EXPECT(dec(a) == sum);
+        evaluator.sub_plain(c1, Plaintext(m2), s2);
+        EXPECT(dec(s2) == diff);
+        evaluator.sub_plain_inplace(a, Plaintext(m2));
+        EXPECT(dec(a) == m1);
+        Ciphertext low(c1);
+        evaluator.mod_switch_to_next_inplace(low);
+        evaluator.add_plain_inplace(low, Plaintext(m2));
+        EXPECT(low.coeff_modulus_size() == L - 1 && dec(low) == sum);
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.add_plain_inplace(a, Plaintext(vec{ t })); }));
+        // the product with a plaintext added, at the product's correction factor
+        Ciphertext pa(prod);
+        evaluator.add_plain_inplace(pa, Plaintext(m2));
+        vec e2(exp);
+        for (size_t i = 0; i < m2.size(); ++i)
+            e2[i] = (e2[i] + m2[i]) % t;
+        EXPECT(dec(pa) == e2);
+    }
+
     const std::string tag = scheme == scheme_type::bfv ? "bfv" : "bgv";
     auto write_ct = [&](const std::string &name, const Ciphertext &ct) {
         std::ofstream f(dir + "/facade_" + tag + "_" + name + ".bin", std::ios::binary);
