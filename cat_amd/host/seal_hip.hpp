@@ -986,8 +986,21 @@ namespace seal
         void multiply_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const
         {
             verify(encrypted, "encrypted");
-            if (!encrypted.is_ntt_form() || !plain.is_ntt_form())
-                throw std::invalid_argument(encrypted.is_ntt_form() ? "plain_ntt is not in NTT form" : "NTT form mismatch");
+            if (!plain.is_ntt_form())
+            {
+                // coefficient-form plaintext modulo t (BFV / BGV): multiply_plain_normal :1985-2133, or the lifted
+                // plaintext's transform against an NTT-form ciphertext :1972-1977
+                multiply_plain_coeff(encrypted, plain);
+                return;
+            }
+            if (!encrypted.is_ntt_form())
+            {
+                // :1978-1983
+                transform_to_ntt_inplace(encrypted);
+                multiply_plain_inplace(encrypted, plain);
+                transform_from_ntt_inplace(encrypted);
+                return;
+            }
             if (encrypted.coeff_modulus_size() != plain.coeff_modulus_size())
                 throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
             detail::check(cat_multiply_plain_ntt(h(), encrypted.d_data(), plain.d_data(), 0, encrypted.d_data(),
@@ -1608,6 +1621,7 @@ namespace seal
         // BFV / BGV branches of add_plain / sub_plain (coefficient-form plaintext modulo t, evaluator.cpp:1737-1951);
         // defined in seal_hip_crypto.hpp next to the plaintext scaling / lifting it shares with Encryptor
         void plain_addsub_coeff(Ciphertext &encrypted, const Plaintext &plain, bool sub) const;
+        void multiply_plain_coeff(Ciphertext &encrypted, const Plaintext &plain) const;
         void plain_addsub(Ciphertext &encrypted, const Plaintext &plain, bool sub) const
         {
             verify(encrypted, "encrypted");

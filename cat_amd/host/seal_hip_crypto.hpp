@@ -762,6 +762,38 @@ namespace seal
         detail::check(cat_stream_sync(context_.handle(), nullptr));
     }
 
+    // Evaluator::multiply_plain_inplace with a coefficient-form plaintext modulo t (evaluator.cpp:1953-2133): the
+    // plaintext is lifted (coefficients at or above (t + 1) / 2 stand for negatives) and transformed once; an NTT-form
+    // ciphertext is multiplied as it is, a coefficient-form one through forward transform, product, inverse transform
+    // per polynomial.  (The reference's monomial shortcut gives the same words: both are exact modulo q.)
+    inline void Evaluator::multiply_plain_coeff(Ciphertext &encrypted, const Plaintext &plain) const
+    {
+        const std::size_t L = encrypted.coeff_modulus_size(), n = context_.poly_modulus_degree();
+        const std::uint64_t t = context_.parms().plain_modulus();
+        if (context_.parms().scheme() == scheme_type::ckks || t == 0)
+            throw std::invalid_argument("plain is not valid for encryption parameters");
+        if (plain.coeff_count() > n || plain.coeff_count() == 0)
+            throw std::invalid_argument("plain is not valid for encryption parameters");
+        for (std::uint64_t c : plain.data())
+            if (c >= t)
+                throw std::invalid_argument("plain is not valid for encryption parameters");
+        const detail::PlainTools tools(detail::level_primes(context_, L), t, 0);
+        std::vector<std::uint64_t> lifted(L * n);
+        tools.lift_plain(plain.data(), n, lifted.data());
+        detail::DeviceWords d_plain(context_.handle(), lifted);
+        cat_ctx *c = context_.handle();
+        const std::uint32_t size = (std::uint32_t)encrypted.size();
+        detail::check(cat_ntt_forward(c, d_plain.get(), nullptr, (std::uint32_t)L, 1, 0, nullptr));
+        const bool coeff_form = !encrypted.is_ntt_form();
+        if (coeff_form)
+            detail::check(cat_ntt_forward(c, encrypted.d_data(), nullptr, (std::uint32_t)L, size, 0, nullptr));
+        detail::check(cat_multiply_plain_ntt(c, encrypted.d_data(), d_plain.get(), 0, encrypted.d_data(), (std::uint32_t)L, size, 1,
+                                             nullptr));
+        if (coeff_form)
+            detail::check(cat_ntt_inverse(c, encrypted.d_data(), nullptr, (std::uint32_t)L, size, 0, nullptr));
+        detail::check(cat_stream_sync(c, nullptr));
+    }
+
     class Decryptor
     {
     public:

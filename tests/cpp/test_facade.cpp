@@ -968,6 +968,16 @@ static void test_plain_modes(const std::string &dir, scheme_type scheme)
         evaluator.add_plain_inplace(low, Plaintext(m2));
         EXPECT(low.coeff_modulus_size() == L - 1 && dec(low) == sum);
         EXPECT(throws<std::invalid_argument>([&] { evaluator.add_plain_inplace(a, Plaintext(vec{ t })); }));
+        // multiply_plain with a coefficient-form plaintext (evaluator.cpp:1953-2133): the negacyclic product modulo t
+        Ciphertext mp;
+        evaluator.multiply_plain(c1, Plaintext(m2), mp);
+        EXPECT(mp.size() == 2 && mp.is_ntt_form() == c1.is_ntt_form() && dec(mp) == exp);
+        Ciphertext mono(c1);
+        evaluator.multiply_plain_inplace(mono, Plaintext(vec{ 0, 0, 0, 5 })); // 5 x^3: the reference's monomial case
+        vec em(n);
+        for (size_t i = 0; i < n; ++i)
+            em[(i + 3) % n] = i + 3 < n ? m1[i] * 5 % t : (t - m1[i] * 5 % t) % t;
+        EXPECT(dec(mono) == em);
         // the product with a plaintext added, at the product's correction factor
         Ciphertext pa(prod);
         evaluator.add_plain_inplace(pa, Plaintext(m2));
