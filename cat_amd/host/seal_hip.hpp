@@ -1622,6 +1622,18 @@ namespace seal
         // defined in seal_hip_crypto.hpp next to the plaintext scaling / lifting it shares with Encryptor
         void plain_addsub_coeff(Ciphertext &encrypted, const Plaintext &plain, bool sub) const;
         void multiply_plain_coeff(Ciphertext &encrypted, const Plaintext &plain) const;
+
+    public:
+        // evaluator.cpp:2174-2265: a coefficient-form plaintext modulo t lifted to the level parms_id names and
+        // transformed (defined in seal_hip_crypto.hpp like the branches above)
+        void transform_to_ntt_inplace(Plaintext &plain, const parms_id_type &parms_id) const;
+        void transform_to_ntt(const Plaintext &plain, const parms_id_type &parms_id, Plaintext &destination_ntt) const
+        {
+            destination_ntt = plain;
+            transform_to_ntt_inplace(destination_ntt, parms_id);
+        }
+
+    private:
         void plain_addsub(Ciphertext &encrypted, const Plaintext &plain, bool sub) const
         {
             verify(encrypted, "encrypted");

@@ -794,6 +794,29 @@ namespace seal
         detail::check(cat_stream_sync(c, nullptr));
     }
 
+    inline void Evaluator::transform_to_ntt_inplace(Plaintext &plain, const parms_id_type &parms_id) const
+    {
+        const std::size_t L = context_.level_of(parms_id), n = context_.poly_modulus_degree();
+        const std::uint64_t t = context_.parms().plain_modulus();
+        if (!L)
+            throw std::invalid_argument("parms_id is not valid for the current context");
+        if (plain.is_ntt_form())
+            throw std::invalid_argument("plain is already in NTT form");
+        if (context_.parms().scheme() == scheme_type::ckks || t == 0 || plain.coeff_count() > n)
+            throw std::invalid_argument("plain is not valid for encryption parameters");
+        for (std::uint64_t c : plain.data())
+            if (c >= t)
+                throw std::invalid_argument("plain is not valid for encryption parameters");
+        const detail::PlainTools tools(detail::level_primes(context_, L), t, 0);
+        std::vector<std::uint64_t> lifted(L * n);
+        tools.lift_plain(plain.data(), n, lifted.data());
+        Plaintext dest(context_, L);
+        dest.upload(lifted.data());
+        detail::check(cat_ntt_forward(context_.handle(), dest.d_data(), nullptr, (std::uint32_t)L, 1, 0, nullptr));
+        detail::check(cat_stream_sync(context_.handle(), nullptr));
+        plain = std::move(dest);
+    }
+
     class Decryptor
     {
     public:

@@ -978,6 +978,14 @@ static void test_plain_modes(const std::string &dir, scheme_type scheme)
         for (size_t i = 0; i < n; ++i)
             em[(i + 3) % n] = i + 3 < n ? m1[i] * 5 % t : (t - m1[i] * 5 % t) % t;
         EXPECT(dec(mono) == em);
+        // the same product with the plaintext transformed first (evaluator.cpp:2174-2265, then :1967-1983)
+        Plaintext m2_ntt;
+        evaluator.transform_to_ntt(Plaintext(m2), c1.parms_id(), m2_ntt);
+        EXPECT(m2_ntt.is_ntt_form() && m2_ntt.coeff_modulus_size() == L && m2_ntt.parms_id() == c1.parms_id());
+        Ciphertext mp2(c1);
+        evaluator.multiply_plain_inplace(mp2, m2_ntt);
+        EXPECT(mp2.is_ntt_form() == c1.is_ntt_form() && mp2.to_cpu() == mp.to_cpu() && dec(mp2) == exp);
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.transform_to_ntt_inplace(m2_ntt, c1.parms_id()); }));
         // the product with a plaintext added, at the product's correction factor
         Ciphertext pa(prod);
         evaluator.add_plain_inplace(pa, Plaintext(m2));
