@@ -53,6 +53,7 @@ SIGNATURES = {
     "cat_relinearize": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_relinearize_rescale": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_rescale": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
+    "cat_rescale_noalloc": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "cat_rescale_strided": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "cat_mod_drop": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "cat_galois_elt_from_step": (C.c_uint32, [C.c_uint32, C.c_int]),

@@ -257,6 +257,14 @@ class Context:
         _check(self.lib.cat_rescale(self.h, self._p(ct), self._p(out), L, size, b, self._stream()))
         return out
 
+    NOALLOC_SCRATCH_BYTES = 64 << 20  # CAT_NOALLOC_SCRATCH_BYTES (include/cat_amd.h)
+
+    def rescale_noalloc(self, ct, out):
+        """cat_rescale_noalloc: `out` is required (this path allocates nothing, torch included)."""
+        b, size, L, _ = ct.shape
+        _check(self.lib.cat_rescale_noalloc(self.h, self._p(ct), self._p(out), L, size, b, self._stream()))
+        return out
+
     def rescale_strided(self, ct, size, out):
         """ct: [batch, S, L, N] of which the first `size` polys are the ciphertext (stride S*L*N)."""
         b, S, L, _ = ct.shape

@@ -3,6 +3,7 @@
 #include "context.hpp"
 
 #include <cstring>
+#include <mutex>
 #include <new>
 
 using namespace cat;
@@ -10,6 +11,41 @@ using namespace cat;
 namespace
 {
     thread_local std::string g_last_error;
+}
+
+// ---- scratch of the no-allocation entry point (cat_rescale_noalloc) ------------------------------------------
+// One file-scope device array per GPU the library runs on, held until the process ends.  `cat_noalloc_scratch` is a
+// host-side stand-in for the symbol, NOT a device address: host code only ever uses the per-device address that
+// noalloc_scratch_init() obtained with hipGetSymbolAddress (each GPU has its own copy at its own address).
+static __device__ __align__(256) unsigned char cat_noalloc_scratch[CAT_NOALLOC_SCRATCH_BYTES];
+
+namespace
+{
+    constexpr int MAX_DEVICES = 64;
+    std::mutex g_scratch_mutex;
+    void *g_scratch_ptr[MAX_DEVICES] = {};
+
+    // once per device, with that device current (called from cat_ctx_create after hipSetDevice)
+    cat_status noalloc_scratch_init(int device)
+    {
+        if (device < 0 || device >= MAX_DEVICES)
+            return CAT_OK; // such a device simply has no no-allocation entry point (it reports that itself)
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (g_scratch_ptr[device])
+            return CAT_OK;
+        void *p = nullptr;
+        CAT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(cat_noalloc_scratch)));
+        g_scratch_ptr[device] = p;
+        return CAT_OK;
+    }
+
+    void *noalloc_scratch(int device)
+    {
+        if (device < 0 || device >= MAX_DEVICES)
+            return nullptr;
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        return g_scratch_ptr[device];
+    }
 }
 
 namespace cat
@@ -140,6 +176,11 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
     if ((scheme == CAT_SCHEME_BFV || scheme == CAT_SCHEME_BGV) && (plain_modulus < 2 || (plain_modulus >> 60) != 0))
         return fail(CAT_ERR_INVALID_ARG, "plain_modulus is invalid");
     CAT_HIP(hipSetDevice(device));
+    {
+        const cat_status st = noalloc_scratch_init(device);
+        if (st != CAT_OK)
+            return st;
+    }
 
     cat_ctx *ctx = new (std::nothrow) cat_ctx();
     if (!ctx)
@@ -683,6 +724,29 @@ cat_status cat_rescale(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
     return launch_rescale(ctx, (const u64 *)in, (u64 *)out, L, size, batch, (size_t)size * L * ctx->n,
                           (size_t)size * (L - 1) * ctx->n, (hipStream_t)s);
+}
+
+cat_status cat_rescale_noalloc(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t L, uint32_t size, uint32_t batch,
+                               cat_stream s)
+{
+    // cat_rescale with its temporaries in the static device array above: no hipMalloc / hipFree / allocating
+    // library routine on this path (argument checks, kernel launches and nothing else)
+    cat_status st = check(ctx);
+    if (st != CAT_OK)
+        return st;
+    if ((st = level_check(ctx, L, true)) != CAT_OK)
+        return st;
+    if (size * batch && (!in || !out))
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    void *scratch = noalloc_scratch(ctx->device);
+    if (!scratch)
+        return fail(CAT_ERR_LOGIC, "no static scratch buffer on this device");
+    // (polys last limbs) + (polys x (L-1) correction limbs), the same sum launch_rescale checks
+    const unsigned __int128 need = (unsigned __int128)size * batch * L * ctx->n * sizeof(u64);
+    if (need > CAT_NOALLOC_SCRATCH_BYTES)
+        return fail(CAT_ERR_INVALID_ARG, "operands exceed the static scratch buffer");
+    return launch_rescale(ctx, (const u64 *)in, (u64 *)out, L, size, batch, (size_t)size * L * ctx->n,
+                          (size_t)size * (L - 1) * ctx->n, (hipStream_t)s, (u64 *)scratch, CAT_NOALLOC_SCRATCH_BYTES);
 }
 
 cat_status cat_rescale_strided(cat_ctx *ctx, const uint64_t *in, size_t in_stride, uint64_t *out, size_t out_stride,

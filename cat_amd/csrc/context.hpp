@@ -159,8 +159,11 @@ namespace cat
     cat_status launch_switch_key(cat_ctx *ctx, u64 *enc, const u64 *target, const u64 *key, uint32_t L, uint32_t batch,
                                  size_t enc_stride, size_t target_stride, hipStream_t s, u64 *rescale_out = nullptr,
                                  size_t out_stride = 0);
+    // scratch != nullptr: temporaries come from that caller-provided device block of scratch_bytes bytes instead of the
+    // context workspace (the no-allocation entry point, capi.cpp); input and output must then not overlap
     cat_status launch_rescale(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t size, uint32_t batch,
-                              size_t in_stride, size_t out_stride, hipStream_t s);
+                              size_t in_stride, size_t out_stride, hipStream_t s, u64 *scratch = nullptr,
+                              size_t scratch_bytes = 0);
     enum { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_DYADIC = 3, EW_MODULO = 4, SCALAR_MUL = 0, SCALAR_ADD = 1, SCALAR_SUB = 2 };
 } // namespace cat
 

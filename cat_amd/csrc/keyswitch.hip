@@ -933,7 +933,7 @@ namespace cat
     }
 
     cat_status launch_rescale(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t size, uint32_t batch,
-                              size_t in_stride, size_t out_stride, hipStream_t s)
+                              size_t in_stride, size_t out_stride, hipStream_t s, u64 *scratch, size_t scratch_bytes)
     {
         const size_t N = ctx->n;
         const u64 polys = (u64)batch * size;
@@ -944,10 +944,19 @@ namespace cat
         const bool alias = !(out_end <= in || in_end <= out);
         const bool ckks = ctx->scheme != CAT_SCHEME_BFV;
         const bool bgv = ctx->scheme == CAT_SCHEME_BGV;
-        u64 *ws = (u64 *)workspace(ctx, (w_last + 2 * w_tmp) * sizeof(u64));
+        u64 *ws = scratch;
+        if (scratch)
+        {
+            if (alias)
+                return fail(CAT_ERR_INVALID_ARG, "destination must not alias the inputs");
+            if ((w_last + w_tmp) * sizeof(u64) > scratch_bytes)
+                return fail(CAT_ERR_INVALID_ARG, "operands exceed the static scratch buffer");
+        }
+        else
+            ws = (u64 *)workspace(ctx, (w_last + 2 * w_tmp) * sizeof(u64));
         if (!ws)
             return CAT_ERR_NOMEM;
-        u64 *last = ws, *tmp = last + w_last, *stage = tmp + w_tmp;
+        u64 *last = ws, *tmp = last + w_last, *stage = tmp + w_tmp; // stage is used only when alias (never with scratch)
         RescaleArgs g;
         g.in = in;
         g.last = last;

@@ -188,6 +188,17 @@ cat_status cat_rescale(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint
  * evaluator.cpp:1191, leaves the third polynomial in place). */
 cat_status cat_rescale_strided(cat_ctx *ctx, const uint64_t *d_in, size_t in_stride, uint64_t *d_out,
                                size_t out_stride, uint32_t L, uint32_t size, uint32_t batch, cat_stream s);
+/* No counterpart in the reference.  cat_rescale for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same words in d_out; its temporaries
+ * (batch x size last limbs and batch x size x (L-1) correction limbs) live in a static device array of
+ * CAT_NOALLOC_SCRATCH_BYTES per GPU instead of the context workspace, so the call performs no hipMalloc / hipFree and
+ * never synchronises.  Limits: batch * size * L * N * 8 bytes <= CAT_NOALLOC_SCRATCH_BYTES (else CAT_ERR_INVALID_ARG,
+ * "operands exceed the static scratch buffer"); d_out must not overlap d_in (CAT_ERR_INVALID_ARG).  Every call on a GPU
+ * shares that GPU's array, from any context or thread: calls that overlap in time on one GPU race.  Nothing in the array
+ * needs to start at zero (every word is written before it is read within a call). */
+#define CAT_NOALLOC_SCRATCH_BYTES (64u << 20)
+cat_status cat_rescale_noalloc(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t size,
+                               uint32_t batch, cat_stream s);
 /* Evaluator::mod_switch_drop_to_next (evaluator.cpp:1282-1345): drop the last limb of every poly. */
 cat_status cat_mod_drop(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t size,
                         uint32_t batch, cat_stream s);
