@@ -140,7 +140,7 @@ namespace
     template <bool WIDE>
     __global__ __launch_bounds__(256, 2) void ks_rows_mac_kernel(RowsMacArgs g)
     {
-        __shared__ u64 lds[RM_TW_WORDS + RM_X_WORDS];
+        __shared__ __align__(16) u64 lds[RM_TW_WORDS + RM_X_WORDS];
         // id -> (group, ciphertext): ids 8 apart share the group (= the key tile) and the XCD
         const u32 chunk = blockIdx.x / (8 * g.batch), within = blockIdx.x - chunk * 8 * g.batch;
         const u32 b = within >> 3, grp = chunk * 8 + (within & 7);
@@ -708,8 +708,7 @@ namespace cat
         }
         // step 2: modulus raise fused into the first NTT pass (ntt.hip Source): ext is written once, already
         // half transformed, instead of being written by a raise kernel and re-read
-        static const bool unfused = getenv("CAT_KS_UNFUSED") != nullptr;
-        const bool fused_mac = log_n >= 12 && !unfused;
+        const bool fused_mac = log_n >= 12;
         bool wide = false;
         {
             LimbMap map{};

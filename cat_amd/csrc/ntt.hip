@@ -39,6 +39,31 @@ namespace
 #define ROWS8_TARGET_BLOCKS 8192 // poly-streaming row passes: workgroups aimed at (4096 and 16384 measured 1 % slower)
 #endif
 
+    // streaming accesses of the poly-streaming row passes (data touched once per launch): non-temporal hints
+#ifdef CAT_NO_NT
+#define NT_LOAD(p) (*(p))
+#define NT_STORE(v, p) (*(p) = (v))
+#else
+#define NT_LOAD(p) __builtin_nontemporal_load(p)
+#define NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ ulonglong2 NT_LOAD2(const u64 *p)
+    {
+        const u64x2 v = NT_LOAD(reinterpret_cast<const u64x2 *>(p));
+        ulonglong2 r;
+        r.x = v.x;
+        r.y = v.y;
+        return r;
+    }
+    __device__ __forceinline__ void NT_STORE2(const ulonglong2 &w, u64 *p)
+    {
+        u64x2 v;
+        v.x = w.x;
+        v.y = w.y;
+        NT_STORE(v, reinterpret_cast<u64x2 *>(p));
+    }
+
     struct NttArgs
     {
         u64 *data;
@@ -115,6 +140,15 @@ namespace
         __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // Workgroup barrier that orders LDS accesses only: global loads already requested stay in flight across it
+    // (__syncthreads() also waits for every outstanding global access of the wave).
+    __device__ __forceinline__ void lds_barrier()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
 
     // x >= K ? x - K : x   (one 64-bit add, one compare, two selects)
@@ -667,41 +701,6 @@ namespace
         fwd_rows_tile<P>(a, w, m, tw, lds);
     }
 
-    // ---- forward, both passes by one workgroup (experiment, CAT_NTT_FUSED=1; N = 2^16, plain in-place transforms) ----
-    // The workgroup owns one limb-polynomial: 16 column tiles, a barrier, 16 row tiles.  Its second pass finds part of
-    // the polynomial in cache (tools/ubench_reuse.hip: 1.38 x on the memory side); the row twiddles come from L2,
-    // which the limb-slowest workgroup order keeps on one prime at a time.  Measured on MI355X, config 2: 15.9 ms
-    // against 15.6 ms for the two launches (130 VGPRs, 3 waves per SIMD; forced to 4 it spills and takes 16.3 ms):
-    // bit-exact, but the time moved from memory to the instruction stream, so it stays off by default.
-    template <class P>
-    __global__ __launch_bounds__(256) void ntt_fwd_fused16(NttArgs a)
-    {
-        constexpr int LDS_WORDS = TILE_WORDS > 16 * ROW_PITCH ? TILE_WORDS : 16 * ROW_PITCH;
-        __shared__ u64 lds[LDS_WORDS];
-        __shared__ u64 twl[3 * 256];
-        Where w = locate(a, blockIdx.x, 1);
-        if (w.skip)
-            return;
-        const typename P::Mod m = P::mod(a.mods[w.mod]);
-        {
-            const typename P::Table twc = stage_col_twiddles(twl, P::table(a.tw, w.mod, a.log_n, false), a.log_n, false);
-            for (u32 tile = 0; tile < 16; ++tile)
-            {
-                w.tile = tile;
-                fwd_cols_tile<P, 8, false>(a, w, m, twc, lds);
-                __syncthreads(); // the tile's LDS exchange is over before the next tile writes
-            }
-        }
-        // workgroup-scope: every column-pass store of this workgroup is visible to its row pass
-        __syncthreads();
-        const typename P::Table tw = P::table(a.tw, w.mod, a.log_n, false);
-        for (u32 tile = 0; tile < 16; ++tile)
-        {
-            w.tile = tile;
-            fwd_rows_tile<P>(a, w, m, tw, lds);
-        }
-    }
-
     // ---- forward, pass 2, poly-streaming form (Fast policy, no fused epilogue) ------------------------------
     // A workgroup owns 8 rows of one limb at one position, stages their twiddles in LDS once (rows8.cuh) and
     // streams the rows of `n_polys / chunks` polynomials through them, two polynomials in flight per thread and
@@ -714,13 +713,13 @@ namespace
         for (int n = 0; n < ND; ++n)
 #pragma unroll
             for (int a = 0; a < 8; ++a)
-                x[n][a] = src[n][a * 32];
+                x[n][a] = NT_LOAD(src[n] + a * 32);
     }
 
     template <bool WIDE>
     __global__ __launch_bounds__(256, 2) void ntt_fwd_rows8(NttArgs a, u32 chunks)
     {
-        __shared__ u64 lds[RM_TW_WORDS + RM_X_WORDS];
+        __shared__ __align__(16) u64 lds[RM_TW_WORDS + RM_X_WORDS];
         const u32 n1 = 1u << (a.log_n - 8), tiles = n1 / RM_ROWS;
         const u32 chunk = blockIdx.x % chunks, rest = blockIdx.x / chunks;
         const u32 tile = rest % tiles, limb = rest / tiles;
@@ -778,19 +777,22 @@ namespace
                     u64 v = x[n][u];
                     if (!lazy)
                         v = guard(guard(v, q << 1, nq << 1), q, nq);
-                    xs[(8 * t + u) ^ (t >> 2)] = v; // element e at e ^ ((e >> 5) & 7)
+                    // element e at e ^ ((e >> 4) & 7): the 16 lanes a ds_write_b64 serves together (t = 16k .. 16k+15)
+                    // then hit 16 different 8-byte bank pairs (with (e >> 5) & 7, lanes t and t + 2 collided), and
+                    // the 16-byte reads below stay conflict-free
+                    xs[(8 * t + u) ^ ((t >> 1) & 7)] = v;
                 }
                 rm_wave_sync();
                 u64 *o = base + (u64)(2 * pi + n) * a.poly_stride;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                 {
-                    const u32 e = (i * 32 + t) * 2, sw = (2 * i + (t >> 4)) & 7;
+                    const u32 e = (i * 32 + t) * 2, sw = (4 * i + (t >> 3)) & 7;
                     const ulonglong2 r = *reinterpret_cast<const ulonglong2 *>(xs + ((e ^ sw) & ~1u));
                     ulonglong2 w;
                     w.x = (sw & 1) ? r.y : r.x;
                     w.y = (sw & 1) ? r.x : r.y;
-                    *reinterpret_cast<ulonglong2 *>(o + e) = w;
+                    NT_STORE2(w, o + e);
                 }
             }
         }
@@ -799,7 +801,7 @@ namespace
     // ---- inverse, pass 1, poly-streaming form: the mirror image of ntt_fwd_rows8 ----------------------------
     __global__ __launch_bounds__(256, 2) void ntt_inv_rows8(NttArgs a, u32 chunks)
     {
-        __shared__ u64 lds[RM_TW_WORDS + RM_X_WORDS];
+        __shared__ __align__(16) u64 lds[RM_TW_WORDS + RM_X_WORDS];
         const u32 n1 = 1u << (a.log_n - 8), tiles = n1 / RM_ROWS;
         const u32 chunk = blockIdx.x % chunks, rest = blockIdx.x / chunks;
         const u32 tile = rest % tiles, limb = rest / tiles;
@@ -829,7 +831,7 @@ namespace
                 const u64 *src = a.src ? in_base + (u64)poly * a.src_stride : base + (u64)poly * a.poly_stride;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    raw[n][i] = *reinterpret_cast<const ulonglong2 *>(src + (i * 32 + t) * 2);
+                    raw[n][i] = NT_LOAD2(src + (i * 32 + t) * 2);
             }
         };
         const u32 pairs = (a.n_polys + 1) / 2;
@@ -870,7 +872,7 @@ namespace
                 u64 *o = base + (u64)(2 * pi + n) * a.poly_stride + t;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    o[e * 32] = x[n][e];
+                    NT_STORE(x[n][e], o + e * 32);
             }
         }
     }
@@ -1082,12 +1084,6 @@ namespace
                                dim3(256), 0, s, a);
     }
 
-    bool rows16_forced()
-    {
-        static const bool on = getenv("CAT_NTT_ROWS16") != nullptr; // A/B switch: 16-per-thread row kernels everywhere
-        return on;
-    }
-
     template <class P>
     cat_status launch_policy(cat_ctx *ctx, bool forward, NttArgs &a, hipStream_t s, bool first_only)
     {
@@ -1121,19 +1117,12 @@ namespace
             default: launch_cols<P, 8>(forward, a, (u32)col_blocks, s); break;
             }
         };
-        static const bool fused16 = getenv("CAT_NTT_FUSED") != nullptr; // experiment: both passes by one workgroup
-        if (forward && fused16 && logn1 == 8 && !first_only && !a.src && !a.ep_dest && n_lp <= 0x7fffffffu)
-        {
-            hipLaunchKernelGGL((ntt_fwd_fused16<P>), dim3((u32)n_lp), dim3(256), 0, s, a);
-            CAT_HIP(hipGetLastError());
-            return CAT_OK;
-        }
         if (forward)
         {
             cols();
             if (first_only)
                 ;
-            else if (std::is_base_of<Fast, P>::value && !a.ep_dest && a.n_polys >= 4 && !rows16_forced())
+            else if (std::is_base_of<Fast, P>::value && !a.ep_dest && a.n_polys >= 4)
             {
                 // poly-streaming row pass: workgroups = limbs x 8-row positions x chunks of the polynomials
                 const u64 groups = (u64)a.n_limbs * (n1 / RM_ROWS);
@@ -1150,7 +1139,7 @@ namespace
         }
         else
         {
-            if (std::is_base_of<Fast, P>::value && a.n_polys >= 4 && !rows16_forced())
+            if (std::is_base_of<Fast, P>::value && a.n_polys >= 4)
             {
                 const u64 groups = (u64)a.n_limbs * (n1 / RM_ROWS);
                 u32 chunks = (u32)((ROWS8_TARGET_BLOCKS + groups - 1) / groups);
@@ -1175,9 +1164,6 @@ namespace cat
 {
     bool ntt_wide(const cat_ctx *ctx, const LimbMap &map, uint32_t n_groups)
     {
-        static const bool off = getenv("CAT_NTT_NARROW") != nullptr;
-        if (off)
-            return false;
         for (uint32_t i = 0; i < n_groups; ++i)
             if (ctx->hmods[map.id[i]].q >> 60)
                 return false;

@@ -13,8 +13,18 @@
 namespace
 {
     constexpr int RM_ROWS = 8;
-    constexpr int RM_TW_WORDS = 3 * RM_ROWS * 256; // [w0 | w1 | q0,q1][row][entry]; entry (1 << S) - 1 + G
+    constexpr int RM_TW_WORDS = 3 * RM_ROWS * 256; // [w0 | w1 | q0,q1][row][entry]; entry = rm_entry(S, G)
     constexpr int RM_X_WORDS = RM_ROWS * 256;
+
+    // LDS position of twiddle (S, G), G < 2^S, inside a row's 256-word block: 2^S + G (groups of 2 and 4 consecutive
+    // twiddles start 16-byte aligned, so they are fetched by ds_read_b128; at 2^S - 1 + G the compiler had to use
+    // ds_read2_b64, whose lane stride of 2 / 4 words is a 2- / 4-way bank conflict); the last stage, where every lane
+    // reads its own four twiddles, keeps pairs (G & 2 = 0) and (G & 2 = 2) in two halves of 64 words so that both 16-byte
+    // reads are consecutive across lanes
+    __device__ __forceinline__ u32 rm_entry(u32 S, u32 G)
+    {
+        return S == 7 ? 128 + ((G >> 2) << 1) + (G & 1) + ((G >> 1) & 1) * 64 : (1u << S) + G;
+    }
 
     // all 256 threads: lds[0 .. RM_TW_WORDS) <- twiddles of rows tile*8 .. tile*8+7; table = u64[3][N] of the limb
     __device__ __forceinline__ void rm_stage_twiddles(u64 *lds, const u64 *table, u32 log_n, u32 tile)
@@ -24,13 +34,14 @@ namespace
         if (e < 255)
         {
             const u32 S = 31 - __clz(e + 1), G = e + 1 - (1u << S);
+            const u32 pos = rm_entry(S, G);
 #pragma unroll
             for (int r = 0; r < RM_ROWS; ++r)
             {
                 const u32 idx = ((n1 + tile * RM_ROWS + r) << S) + G;
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
-                    lds[(a * RM_ROWS + r) * 256 + e] = table[((size_t)a << log_n) + idx];
+                    lds[(a * RM_ROWS + r) * 256 + pos] = table[((size_t)a << log_n) + idx];
             }
         }
     }
@@ -43,17 +54,22 @@ namespace
 
     // one radix-2 stage over the 8 registers of ND digits: CNT twiddles, register gap 4 / CNT
     // GM: guard of the additive operand: 0 none, 1 subtract K = 4q, 2 subtract 8q (wide ranges, ntt.hip policy Wide)
+    // entry2: position of twiddles 2, 3 when CNT == 4 (entry + 2 except in the last stage, see rm_entry)
     template <int ND, int CNT, int GM = 1>
-    __device__ __forceinline__ void rm_stage(u64 (&x)[ND][8], const u64 *tw, u32 entry, u64 K, u64 negK, u64 nq)
+    __device__ __forceinline__ void rm_stage(u64 (&x)[ND][8], const u64 *tw, u32 entry, u64 K, u64 negK, u64 nq,
+                                             u32 entry2 = 0xffffffffu)
     {
         constexpr int gap = 4 / CNT;
         MulOp3 w[CNT];
+        if (entry2 == 0xffffffffu)
+            entry2 = entry + 2;
 #pragma unroll
         for (int g = 0; g < CNT; ++g)
         {
-            const u64 qq = tw[2 * RM_ROWS * 256 + entry + g];
-            w[g].w0 = tw[entry + g];
-            w[g].w1 = tw[RM_ROWS * 256 + entry + g];
+            const u32 at = g < 2 ? entry + g : entry2 + (g - 2);
+            const u64 qq = tw[2 * RM_ROWS * 256 + at];
+            w[g].w0 = tw[at];
+            w[g].w1 = tw[RM_ROWS * 256 + at];
             w[g].q0 = (u32)qq;
             w[g].q1 = (u32)(qq >> 32);
         }
@@ -86,9 +102,9 @@ namespace
     __device__ __forceinline__ void rm_rows(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q)
     {
         const u64 K = q << 2, negK = 0 - K, nq = 0 - q;
-        rm_stage<ND, 1, WIDE ? 2 : 1>(x, tw, 0, K, negK, nq);
-        rm_stage<ND, 2, WIDE ? 0 : 1>(x, tw, 1, K, negK, nq);
-        rm_stage<ND, 4, WIDE ? 2 : 1>(x, tw, 3, K, negK, nq);
+        rm_stage<ND, 1, WIDE ? 2 : 1>(x, tw, 1, K, negK, nq);
+        rm_stage<ND, 2, WIDE ? 0 : 1>(x, tw, 2, K, negK, nq);
+        rm_stage<ND, 4, WIDE ? 2 : 1>(x, tw, 4, K, negK, nq);
         const u32 A = t >> 2, c = t & 3;
 #pragma unroll
         for (int n = 0; n < ND; ++n)
@@ -102,9 +118,9 @@ namespace
             for (int b = 0; b < 8; ++b)
                 x[n][b] = xs[(A << 5) | ((b ^ A) << 2) | c]; // element A*32 + 4b + c
         }
-        rm_stage<ND, 1, WIDE ? 0 : 1>(x, tw, 7 + A, K, negK, nq);
-        rm_stage<ND, 2, WIDE ? 2 : 1>(x, tw, 15 + 2 * A, K, negK, nq);
-        rm_stage<ND, 4, WIDE ? 0 : 1>(x, tw, 31 + 4 * A, K, negK, nq);
+        rm_stage<ND, 1, WIDE ? 0 : 1>(x, tw, 8 + A, K, negK, nq);
+        rm_stage<ND, 2, WIDE ? 2 : 1>(x, tw, 16 + 2 * A, K, negK, nq);
+        rm_stage<ND, 4, WIDE ? 0 : 1>(x, tw, 32 + 4 * A, K, negK, nq);
         const u32 bh = t & 3; // reader t = A*4 + b_hi holds elements 8t + u
 #pragma unroll
         for (int n = 0; n < ND; ++n)
@@ -118,8 +134,8 @@ namespace
             for (int u = 0; u < 8; ++u)
                 x[n][u] = xs[(u << 5) | (A << 2) | (bh ^ (u & 3))];
         }
-        rm_stage<ND, 2, WIDE ? 2 : 1>(x, tw, 63 + 2 * t, K, negK, nq);
-        rm_stage<ND, 4, WIDE ? 0 : 1>(x, tw, 127 + 4 * t, K, negK, nq);
+        rm_stage<ND, 2, WIDE ? 2 : 1>(x, tw, 64 + 2 * t, K, negK, nq);
+        rm_stage<ND, 4, WIDE ? 0 : 1>(x, tw, 128 + 2 * t, K, negK, nq, 192 + 2 * t);
 #pragma unroll
         for (int n = 0; n < ND; ++n)
 #pragma unroll

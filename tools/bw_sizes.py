@@ -28,7 +28,7 @@ primes = get_primes_desc(2 * N, 60, 32)
 ctx = cat_amd.Context(LOG_N, primes, cat_amd.SCHEME_NONE, device=0)
 gen = torch.Generator(device="cuda:0"); gen.manual_seed(1)
 for polys in (16, 64, 256, 1024):
-    data = uniform_limbs(torch, primes, (polys,), torch.device("cuda:0"), gen)
+    data = uniform_limbs(torch, primes, (polys,), N, torch.device("cuda:0"), gen)
     f = t(lambda: ctx.ntt_forward(data), 3)
     print(f"NTT {polys:5d} polys ({data.numel()*8/2**30:5.2f} GiB): fwd {f:.3f} ms = {16*data.numel()/f/1e6:.0f} GB/s algorithmic", flush=True)
     del data

@@ -24,9 +24,9 @@ def main():
     gen.manual_seed(1)
     primes = list(reversed(get_primes_desc(2 * N, 60, k)))
     ctx = cat_amd.Context(LOG_N, primes, cat_amd.SCHEME_CKKS, device=0)
-    key = uniform_limbs(torch, primes, (k - 1, 2), device, gen)
-    x = uniform_limbs(torch, primes[:L], (B, 2), device, gen)
-    y = uniform_limbs(torch, primes[:L], (B, 2), device, gen)
+    key = uniform_limbs(torch, primes, (k - 1, 2), N, device, gen)
+    x = uniform_limbs(torch, primes[:L], (B, 2), N, device, gen)
+    y = uniform_limbs(torch, primes[:L], (B, 2), N, device, gen)
     prod = torch.empty((B, 3, L, N), dtype=torch.int64, device=device)
     out = torch.empty((B, 2, L - 1, N), dtype=torch.int64, device=device)
 

@@ -17,7 +17,7 @@ primes = get_primes_desc(2 * N, 60, 32)
 ctx = cat_amd.Context(LOG_N, primes, cat_amd.SCHEME_NONE, device=0)
 gen = torch.Generator(device="cuda:0")
 gen.manual_seed(1)
-data = uniform_limbs(torch, primes, (polys,), torch.device("cuda:0"), gen)
+data = uniform_limbs(torch, primes, (polys,), N, torch.device("cuda:0"), gen)
 ref = data.clone()
 for _ in range(reps):
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))

@@ -66,6 +66,20 @@ KERNEL32(k_pk_mad_u16, "v_pk_mad_u16 %0, %0, %1, %2")
 KERNEL32(k_fma_f32, "v_fma_f32 %0, %0, %1, %2")
 KERNEL32(k_dot4_u32_u8, "v_dot4_u32_u8 %0, %0, %1, %2")
 
+KERNEL32(k_and_b32, "v_and_b32 %0, %0, %1")
+KERNEL32(k_ashrrev_i32, "v_ashrrev_i32 %0, 31, %0")
+KERNEL32(k_cmp_lt_i32, "v_cmp_lt_i32 vcc, %0, %1")
+KERNEL32(k_cvt_f32_u32, "v_cvt_f32_u32 %0, %0")
+KERNEL32(k_cvt_u32_f32, "v_cvt_u32_f32 %0, %0")
+KERNEL32(k_mul_f32, "v_mul_f32 %0, %0, %1")
+KERNEL32(k_not_b32, "v_not_b32 %0, %0")
+KERNEL32(k_sub_co, "v_sub_co_u32 %0, vcc, %0, %1")
+KERNEL32(k_subb_co, "v_subb_co_u32 %0, vcc, %0, %1, vcc")
+KERNEL32(k_bfe_u32, "v_bfe_u32 %0, %0, 3, 9")
+KERNEL32(k_lshrrev_b32, "v_lshrrev_b32 %0, 28, %0")
+KERNEL32(k_and_or_b32, "v_and_or_b32 %0, %0, %1, %2")
+KERNEL32(k_mov_b32, "v_mov_b32 %0, %1")
+
 KERNEL64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
 KERNEL64(k_mad_u64_u32_z, "v_mad_u64_u32 %0, vcc, %1, %2, 0")
 KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %3")
@@ -107,6 +121,8 @@ int main()
 #define R(k) run(#k, k, buf, 4);
     R(k_add_u32) R(k_add3_u32) R(k_mul_lo_u32) R(k_mul_hi_u32) R(k_mul_u32_u24) R(k_mul_hi_u32_u24) R(k_mad_u32_u24)
     R(k_cndmask) R(k_min_u32) R(k_add_co) R(k_addc_co) R(k_cmp_u32) R(k_alignbit) R(k_xor) R(k_lshl_add) R(k_sub_nc)
+    R(k_and_b32) R(k_ashrrev_i32) R(k_cmp_lt_i32) R(k_cvt_f32_u32) R(k_cvt_u32_f32) R(k_mul_f32) R(k_not_b32) R(k_sub_co)
+    R(k_subb_co) R(k_bfe_u32) R(k_lshrrev_b32) R(k_and_or_b32) R(k_mov_b32)
     R(k_mul_lo_u16) R(k_mad_u16) R(k_pk_mul_lo_u16) R(k_pk_mad_u16) R(k_fma_f32) R(k_dot4_u32_u8)
     R(k_mad_u64_u32) R(k_mad_u64_u32_z) R(k_lshl_add_u64) R(k_cmp_u64) R(k_fma_f64) R(k_mul_f64) R(k_add_f64)
     R(k_pk_fma_f32) R(k_lshlrev_b64) R(k_mov_b64) R(k_pk_add_u32x)
