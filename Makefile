@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude
-SRC := cat_amd/csrc/capi.cpp cat_amd/csrc/ntt.hip cat_amd/csrc/polyops.hip cat_amd/csrc/keyswitch.hip cat_amd/csrc/bfv.hip
+SRC := cat_amd/csrc/capi.cpp cat_amd/csrc/comm.cpp cat_amd/csrc/ntt.hip cat_amd/csrc/polyops.hip cat_amd/csrc/keyswitch.hip cat_amd/csrc/bfv.hip
 HDR := include/cat_amd.h cat_amd/csrc/context.hpp cat_amd/csrc/host_math.hpp cat_amd/csrc/modarith.cuh cat_amd/csrc/rows8.cuh
 OBJ := $(patsubst cat_amd/csrc/%,build/%.o,$(SRC))
 LIB := cat_amd/lib/libcat_amd.so
@@ -11,7 +11,7 @@ all: $(LIB) oracle facade_test random_test
 
 $(LIB): $(OBJ)
 	@mkdir -p cat_amd/lib
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJ)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJ) -ldl
 
 build/%.hip.o: cat_amd/csrc/%.hip $(HDR)
 	@mkdir -p build

@@ -238,6 +238,13 @@ class Context:
         _check(self.lib.cat_switch_key(self.h, self._p(enc), self._p(target), self._p(key), L, b, self._stream()))
         return enc
 
+    def key_broadcast(self, key, comm=None, root=0, bucket_words=0):
+        """cat_key_broadcast: replicate `key` from rank `root` of the RCCL communicator `comm` (an ncclComm_t as an
+        integer / c_void_p; None = single process, no-op), in place."""
+        _check(self.lib.cat_key_broadcast(self.h, C.c_void_p(comm) if isinstance(comm, int) else comm, self._p(key),
+                                          key.numel(), root, bucket_words, self._stream()))
+        return key
+
     def relinearize(self, ct3, key):
         """ct3: [batch, 3, L, N]; returns a view of the first two polys (updated in place)."""
         b, _, L, _ = ct3.shape

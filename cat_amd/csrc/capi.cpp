@@ -167,6 +167,13 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
         const uint64_t q = primes[i];
         if (q < 2 || (q >> 61) != 0)
             return fail(CAT_ERR_INVALID_ARG, "value can be at most 61-bit and cannot be 1");
+        // SEAL_USER_MOD_BIT_COUNT_MAX = 60 (util/defines.h:48; context.cu:202-206: invalid_coeff_modulus_bit_count).
+        // It is what keeps the reference's 128-bit lazy accumulators of key switching from wrapping
+        // (evaluator.cpp:2618-2671: up to 256 products of a lazy operand < 4q and a key word < q); with 61-bit primes
+        // and 21 or more digits they do wrap there, and no exact implementation reproduces that.  Contexts without a
+        // scheme (transforms and coefficient-wise operations only) keep the 61-bit limit of Modulus (modulus.cpp:150).
+        if (scheme != CAT_SCHEME_NONE && (q >> 60) != 0)
+            return fail(CAT_ERR_INVALID_ARG, "coeff_modulus primes of a scheme context can be at most 60-bit");
         if ((q - 1) % (2 * n) != 0 || !is_prime_u64(q))
             return fail(CAT_ERR_INVALID_ARG, "invalid modulus");
         for (uint32_t j = 0; j < i; ++j)
@@ -650,7 +657,9 @@ cat_status cat_switch_key(cat_ctx *ctx, uint64_t *enc, const uint64_t *target, c
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
     if (!key)
         return fail(CAT_ERR_INVALID_ARG, "kswitch_keys is not valid for encryption parameters");
-    if (L >= 256)
+    // the lazy accumulators of the inner product hold at most 64 terms without a carry (modarith.cuh: rm_mac); a context
+    // has at most CAT_MAX_MODULI = 64 primes, so L <= 63 here, and the check says so explicitly
+    if (L > CAT_MAX_KEYSWITCH_LIMBS)
         return fail(CAT_ERR_LOGIC, "invalid parameters");
     if (batch == 0)
         return CAT_OK;
@@ -669,7 +678,7 @@ cat_status cat_relinearize(cat_ctx *ctx, uint64_t *ct3, const uint64_t *key, uin
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
     if (ctx->scheme == CAT_SCHEME_NONE || ctx->k < 2)
         return fail(CAT_ERR_LOGIC, "keyswitching is not supported by the context");
-    if (L == 0 || L >= ctx->k || L >= 256)
+    if (L == 0 || L >= ctx->k || L > CAT_MAX_KEYSWITCH_LIMBS)
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
     if (batch == 0)
         return CAT_OK;
@@ -691,7 +700,7 @@ cat_status cat_relinearize_rescale(cat_ctx *ctx, uint64_t *ct3, const uint64_t *
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
     if (ctx->scheme == CAT_SCHEME_NONE || ctx->k < 2)
         return fail(CAT_ERR_LOGIC, "keyswitching is not supported by the context");
-    if (L == 0 || L >= ctx->k || L >= 256)
+    if (L == 0 || L >= ctx->k || L > CAT_MAX_KEYSWITCH_LIMBS)
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
     if (L < 2)
         return fail(CAT_ERR_INVALID_ARG, "end of modulus switching chain reached");

@@ -17,6 +17,9 @@
 #include "rows8.cuh"
 #include <cstdlib>
 
+static_assert(CAT_MAX_KEYSWITCH_LIMBS < CAT_MAX_MODULI && CAT_MAX_KEYSWITCH_LIMBS <= 64,
+              "rm_mac's carry-free high word holds at most 64 terms (modarith.cuh)");
+
 namespace
 {
     struct MacArgs
@@ -137,7 +140,8 @@ namespace
         }
     }
 
-    template <bool WIDE>
+    // Every prime of a scheme context is below 2^60 (cat_ctx_create), so the rows run with the wide lazy ranges and
+    // their results (< 4q < 2^62) meet rm_mac's operand bound as they are.
     __global__ __launch_bounds__(256, 2) void ks_rows_mac_kernel(RowsMacArgs g)
     {
         __shared__ __align__(16) u64 lds[RM_TW_WORDS + RM_X_WORDS];
@@ -218,8 +222,7 @@ namespace
             u64 ka[8], kb[8];
             rm_load8(ka, kp0);
             rm_load8(kb, kp1);
-            rm_rows<2, WIDE>(x, tw, xs, t, q);
-            rm_below_2_62<2>(x, q);
+            rm_rows<2, true>(x, tw, xs, t, q);
 #pragma unroll
             for (int cidx = 0; cidx < 2; ++cidx)
             {
@@ -252,8 +255,7 @@ namespace
 #pragma unroll
             for (int a = 0; a < 8; ++a)
                 x[0][a] = ebase[(size_t)J0 * N + a * 32];
-            rm_rows<1, WIDE>(x, tw, xs, t, q);
-            rm_below_2_62<1>(x, q);
+            rm_rows<1, true>(x, tw, xs, t, q);
             mac(x[0], J0, x[0], J0, false);
         }
         // d < 256: the reference's lazy counter never triggers an intermediate reduction (:2619-2707)
@@ -745,10 +747,9 @@ namespace cat
             const u64 blocks = (u64)((g.groups + 7) / 8) * 8 * batch;
             if (blocks > 0x7fffffffu)
                 return fail(CAT_ERR_LOGIC, "invalid parameters");
-            if (wide)
-                hipLaunchKernelGGL(ks_rows_mac_kernel<true>, dim3((u32)blocks), dim3(256), 0, s, g);
-            else
-                hipLaunchKernelGGL(ks_rows_mac_kernel<false>, dim3((u32)blocks), dim3(256), 0, s, g);
+            if (!wide)
+                return fail(CAT_ERR_LOGIC, "invalid parameters"); // unreachable: scheme contexts hold primes < 2^60
+            hipLaunchKernelGGL(ks_rows_mac_kernel, dim3((u32)blocks), dim3(256), 0, s, g);
             CAT_HIP(hipGetLastError());
         }
         else

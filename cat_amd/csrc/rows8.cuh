@@ -233,19 +233,4 @@ namespace
         rm_stage_inv<ND, 2>(x, tw, 252, K, negK, nq);
         rm_stage_inv<ND, 1>(x, tw, 254, K, negK, nq);
     }
-
-    // 61-bit primes: callers that want the row below 2^62 (rm_mac's bounds) make it canonical
-    template <int ND>
-    __device__ __forceinline__ void rm_below_2_62(u64 (&x)[ND][8], u64 q)
-    {
-        if (q >> 60)
-        {
-            const u64 nq = 0 - q;
-#pragma unroll
-            for (int n = 0; n < ND; ++n)
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    x[n][u] = rm_guard(rm_guard(x[n][u], q << 1, nq << 1), q, nq);
-        }
-    }
 } // namespace

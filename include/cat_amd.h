@@ -47,6 +47,7 @@ typedef enum {
 enum { CAT_SCHEME_NONE = 0, CAT_SCHEME_BFV = 1, CAT_SCHEME_CKKS = 2, CAT_SCHEME_BGV = 3 }; /* scheme_type, encryptionparams.h */
 
 #define CAT_MAX_MODULI 64 /* coefficient primes + BFV auxiliary primes per context */
+#define CAT_MAX_KEYSWITCH_LIMBS 63 /* decomposition digits of one key switch (= ciphertext limbs L); < CAT_MAX_MODULI */
 #define CAT_MAX_LOG_N 16
 #define CAT_MIN_LOG_N 1
 
@@ -160,6 +161,14 @@ cat_status cat_sub_plain(cat_ctx *ctx, const uint64_t *d_ct, const uint64_t *d_p
  * ("keyswitching is not supported by the context", :2543-2546). */
 cat_status cat_switch_key(cat_ctx *ctx, uint64_t *d_encrypted, const uint64_t *d_target, const uint64_t *d_key,
                           uint32_t L, uint32_t batch, cat_stream s);
+/* No counterpart in the reference (single GPU, single process: SURVEY.md 2a).  Replicates a key (or any table of
+ * n_words words) from rank `root` of an RCCL communicator to every rank's d_key, in place, in buckets of bucket_words
+ * words (0 = 256 MB): the one collective of the path, issued once per key outside the steady state.
+ * comm is the caller's ncclComm_t (one rank per GPU, created with ncclCommInitRank); comm == NULL means a single process
+ * and is a no-op.  librccl is bound at run time; CAT_ERR_LOGIC when it cannot be loaded, CAT_ERR_HIP with RCCL's message
+ * when the collective fails.  Asynchronous on stream s like every other call. */
+cat_status cat_key_broadcast(cat_ctx *ctx, void *comm, uint64_t *d_key, size_t n_words, int root, size_t bucket_words,
+                             cat_stream s);
 /* Evaluator::relinearize_internal for size 3 -> 2 (evaluator.cpp:1144-1199): d_ct3 is
  * batch x 3 x L x N; on return the first two polys of each ciphertext hold the result (the caller
  * "resizes" by ignoring the third).  d_key = RelinKeys key of index get_index(2) = 0 (relinkeys.h:58-64). */

@@ -46,9 +46,7 @@ def draw_case(rng, max_log_n):
         k = int(rng.integers(7, 27))  # long chains: the digit loops of key switching (odd and even counts, up to 25 + 1)
     lo = max(log_n + 10, 24) if k < 7 else 40  # enough primes of each size for the chain
     style = rng.random()
-    if scheme == "ckks" and style < 0.15:
-        bits = [61] * k  # SEAL's internal 61-bit primes: the narrow lazy ranges
-    elif style < 0.35:
+    if style < 0.35:
         bits = [60] * k
     else:
         bits = [int(rng.integers(lo, 61)) for _ in range(k)]
@@ -72,10 +70,7 @@ def run_case(cat, so, case, seed):
     log_n, bits, t, batch = case["log_n"], case["bits"], case["t"], case["batch"]
     n = 1 << log_n
     scheme = case["scheme"]
-    if bits[0] == 61:
-        primes = list(reversed(so.get_primes(2 * n, 61, len(bits))))
-    else:
-        primes = so.coeff_modulus_create(n, bits)
+    primes = so.coeff_modulus_create(n, bits)
     oscheme = {"ckks": so.SCHEME_CKKS, "bfv": so.SCHEME_BFV, "bgv": so.SCHEME_BGV}[scheme]
     cscheme = {"ckks": cat.SCHEME_CKKS, "bfv": cat.SCHEME_BFV, "bgv": cat.SCHEME_BGV}[scheme]
     octx = so.Context(log_n, primes, oscheme, t)

@@ -1,0 +1,50 @@
+"""cat_key_broadcast (include/cat_amd.h): key replication over RCCL, the path's only collective.
+A one-GPU box can hold only a one-rank communicator (RCCL refuses two ranks on one device), so this covers the binding
+of librccl at run time, the bucketing and the error path; the multi-rank data movement is the same ncclBroadcast that
+tests/test_sharding_gloo.py exercises through torch.distributed with world size 2."""
+import ctypes as C
+
+import pytest
+import torch
+
+import cat_amd
+
+pytestmark = pytest.mark.gpu
+
+
+class UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+def test_key_broadcast_single_rank_communicator_and_no_comm():
+    n, log_n = 4096, 12
+    import bench
+
+    primes = list(reversed(bench.get_primes_desc(2 * n, 50, 3)))
+    ctx = cat_amd.Context(log_n, primes, cat_amd.SCHEME_CKKS, device=0)
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(1)
+    key = torch.randint(0, min(primes), (2, 2, 3, n), dtype=torch.int64, device="cuda:0", generator=gen)
+    ref = key.clone()
+    ctx.key_broadcast(key)  # no communicator: a single process already holds the key
+    assert torch.equal(key, ref)
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so.1")
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        # several buckets, the last one ragged
+        ctx.key_broadcast(key, comm, root=0, bucket_words=5000)
+        torch.cuda.synchronize()
+        assert torch.equal(key, ref)
+        with pytest.raises(RuntimeError, match="RCCL error"):
+            ctx.key_broadcast(key, comm, root=3)  # no such rank
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+    ctx.close()

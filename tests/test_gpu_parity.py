@@ -285,7 +285,7 @@ def test_ckks_multiply_relinearize_rescale_chain(cat, oracle, log_n, bits):
     (12, [50, 40, 40, 50], "ckks"),
     (13, [60, 40, 40, 60], "ckks"),
     (12, [60, 60, 60, 60, 60], "ckks"),
-    (12, [61, 61, 61, 61], "ckks"),       # 61-bit primes: the narrow lazy ranges
+    (12, [60, 60, 59, 60], "ckks"),       # the largest primes a scheme context accepts, in mixed order
     (12, [30, 45, 30, 55], "ckks"),       # primes of very different sizes: both reduce branches of the round sources
     (10, [30, 27, 30], "ckks"),           # N < 4096: the two steps one after the other
     (12, [40, 40, 40, 41], "bfv"),
@@ -298,10 +298,7 @@ def test_relinearize_rescale_fused_equals_the_two_calls(cat, oracle, log_n, bits
     scheme = {"ckks": (oracle.SCHEME_CKKS, cat.SCHEME_CKKS), "bfv": (oracle.SCHEME_BFV, cat.SCHEME_BFV),
               "bgv": (oracle.SCHEME_BGV, cat.SCHEME_BGV)}[scheme_name]
     t = 0 if scheme_name == "ckks" else 65537
-    if bits == [61, 61, 61, 61]:
-        primes = list(reversed(oracle.get_primes(2 * n, 61, 4)))
-    else:
-        primes = oracle.coeff_modulus_create(n, bits)
+    primes = oracle.coeff_modulus_create(n, bits)
     octx = oracle.Context(log_n, primes, scheme[0], t)
     ctx = cat.Context(log_n, primes, scheme[1], t)
     k = len(primes)
@@ -357,10 +354,10 @@ def test_switch_key_direct_and_rotate(cat, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("log_n,bits,count,batch", [(12, 61, 4, 9), (13, 61, 6, 2), (12, 30, 3, 5)])
+@pytest.mark.parametrize("log_n,bits,count,batch", [(12, 60, 4, 9), (13, 60, 6, 2), (12, 30, 3, 5)])
 def test_switch_key_fused_kernel_prime_sizes(cat, oracle, log_n, bits, count, batch):
-    """The fused row-pass + inner-product kernel at the prime sizes its accumulator bounds distinguish (61-bit
-    primes take the canonical-operand path), with more ciphertexts than XCD groups of 8 and every level."""
+    """The fused row-pass + inner-product kernel at the largest and at small prime sizes, with more ciphertexts than
+    XCD groups of 8 and every level."""
     n = 1 << log_n
     primes = list(reversed(oracle.get_primes(2 * n, bits, count)))
     octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
@@ -377,13 +374,17 @@ def test_switch_key_fused_kernel_prime_sizes(cat, oracle, log_n, bits, count, ba
     ctx.close()
 
 
-@pytest.mark.parametrize("bits", [60, 61])
-def test_switch_key_extreme_operands(cat, oracle, bits):
+@pytest.mark.parametrize("bits,count", [(60, 8), (60, 25), (59, 25), (60, 64), (55, 64)])
+def test_switch_key_extreme_operands(cat, oracle, bits, count):
     """Largest operands the lazy accumulators of the fused key-switch kernel can meet: every key word and every
-    target coefficient equal to q - 1 (and 0 / alternating patterns), at the largest prime sizes."""
+    target coefficient equal to q - 1 (and 0 / alternating patterns), at the largest prime size a scheme context
+    accepts (60 bits, as the reference: util/defines.h:48), with d = 7, with the metric's d = 24 and with d = 63, the
+    most digits a context accepts (CAT_MAX_MODULI = 64 primes; rm_mac's carry-free high word holds 64 terms,
+    modarith.cuh).  (With 61-bit primes the reference's own 128-bit accumulators wrap from d = 21 on for exactly these
+    operands, evaluator.cpp:2618-2671; such contexts are rejected, test_scheme_contexts_reject_61_bit_primes.)"""
     log_n = 12
     n = 1 << log_n
-    primes = list(reversed(oracle.get_primes(2 * n, bits, 8)))
+    primes = list(reversed(oracle.get_primes(2 * n, bits, count)))
     octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
     ctx = cat.Context(log_n, primes, cat.SCHEME_CKKS)
     k = len(primes)
@@ -400,6 +401,17 @@ def test_switch_key_extreme_operands(cat, oracle, bits):
     exp = np.stack([octx.switch_key_inplace(enc[b], tgt[b], key) for b in range(3)])
     assert (got == exp).all()
     ctx.close()
+
+
+def test_scheme_contexts_reject_61_bit_primes(cat, oracle):
+    """context.cu:202-206 (invalid_coeff_modulus_bit_count): user primes are at most 60 bits; a context without a scheme
+    (transforms only) takes the 61-bit primes of Modulus."""
+    n = 4096
+    primes = oracle.get_primes(2 * n, 60, 2) + oracle.get_primes(2 * n, 61, 1)
+    for scheme, t in ((cat.SCHEME_CKKS, 0), (cat.SCHEME_BFV, 65537), (cat.SCHEME_BGV, 65537)):
+        with pytest.raises(ValueError, match="at most 60-bit"):
+            cat.Context(12, primes, scheme, t)
+    cat.Context(12, primes, cat.SCHEME_NONE).close()
 
 
 def test_bfv_switch_key_rescale_and_galois_branches(cat, oracle):

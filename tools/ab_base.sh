@@ -6,8 +6,8 @@ set -e
 cd "$(dirname "$0")/.."
 rev=${1:-HEAD}
 tmp=$(mktemp -d)
-git archive $rev cat_amd/csrc include Makefile oracle/Makefile | tar -x -C $tmp
-mkdir -p $tmp/oracle tools/ab
+git archive $rev cat_amd/csrc include Makefile | tar -x -C $tmp
+mkdir -p tools/ab
 (cd $tmp && make -s -j8 cat_amd/lib/libcat_amd.so >/dev/null)
 cp $tmp/cat_amd/lib/libcat_amd.so tools/ab/libcat_base.so
 rm -rf $tmp
