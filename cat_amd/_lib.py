@@ -21,6 +21,7 @@ SIGNATURES = {
     "cat_ctx_create": (C.c_int, [C.c_uint32, u64p, C.c_uint32, C.c_int, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "cat_ctx_destroy": (C.c_int, [vp]),
     "cat_ctx_reserve": (C.c_int, [vp, C.c_size_t]),
+    "cat_ctx_workspace_need": (C.c_size_t, [vp, C.c_uint32]),
     "cat_ctx_workspace_bytes": (C.c_size_t, [vp]),
     "cat_ctx_log_n": (C.c_uint32, [vp]),
     "cat_ctx_n_primes": (C.c_uint32, [vp]),

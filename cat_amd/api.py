@@ -33,7 +33,8 @@ def galois_elt_from_step(log_n: int, step: int) -> int:
 
 
 def to_device(a: np.ndarray, device="cuda:0") -> torch.Tensor:
-    assert a.dtype == np.uint64
+    if a.dtype != np.uint64:
+        raise ValueError("expected an array of uint64 words")
     return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(device)
 
 
@@ -67,14 +68,26 @@ class Context:
             pass
 
     # -- helpers -------------------------------------------------------------------------------------
-    @staticmethod
-    def _p(t: torch.Tensor):
-        assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()
+    def _p(self, t: torch.Tensor, shape=None):
+        """Device pointer of an operand after the checks the C ABI cannot make: int64 words, contiguous, on this
+        context's device, and (for outputs and fixed-shape operands) exactly the expected shape."""
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous():
+            raise ValueError("operands are contiguous torch.int64 CUDA tensors")
+        if t.device.index != self.device:
+            raise ValueError(f"operand lives on cuda:{t.device.index}, the context on cuda:{self.device}")
+        if t.shape[-1] != self.n:
+            raise ValueError(f"the last dimension must be the polynomial degree {self.n}")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
         return C.c_void_p(t.data_ptr())
 
-    @staticmethod
-    def _stream():
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def _key(self, key: torch.Tensor):
+        """one KSwitchKeys entry: [k-1, 2, k, N] words"""
+        return self._p(key, (self.k - 1, 2, self.k, self.n))
+
+    def _stream(self):
+        # the stream of the CONTEXT's device (every C call makes that device current)
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     @staticmethod
     def _ids(limb_ids):
@@ -110,14 +123,15 @@ class Context:
         out = torch.empty_like(a) if out is None else out
         nl = a.shape[-2]
         npoly = a.numel() // (nl * self.n)
-        _check(fn(self.h, self._p(a), self._p(b), self._p(out), self._ids(limb_ids), nl, npoly, self._stream()))
+        _check(fn(self.h, self._p(a), self._p(b, a.shape), self._p(out, a.shape), self._ids(limb_ids), nl, npoly,
+                  self._stream()))
         return out
 
     def _unary(self, fn, a, out, limb_ids):
         out = torch.empty_like(a) if out is None else out
         nl = a.shape[-2]
         npoly = a.numel() // (nl * self.n)
-        _check(fn(self.h, self._p(a), self._p(out), self._ids(limb_ids), nl, npoly, self._stream()))
+        _check(fn(self.h, self._p(a), self._p(out, a.shape), self._ids(limb_ids), nl, npoly, self._stream()))
         return out
 
     def _scalar(self, fn, a, scalars, out, limb_ids):
@@ -125,7 +139,7 @@ class Context:
         nl = a.shape[-2]
         npoly = a.numel() // (nl * self.n)
         sc = (C.c_uint64 * nl)(*[int(s) for s in scalars])
-        _check(fn(self.h, self._p(a), sc, self._p(out), self._ids(limb_ids), nl, npoly, self._stream()))
+        _check(fn(self.h, self._p(a), sc, self._p(out, a.shape), self._ids(limb_ids), nl, npoly, self._stream()))
         return out
 
     def add(self, a, b, out=None, limb_ids=None):
@@ -157,14 +171,16 @@ class Context:
         """x, y: [batch, 2, L, N] -> [batch, 3, L, N]"""
         b, _, L, _ = x.shape
         out = torch.empty((b, 3, L, self.n), dtype=torch.int64, device=x.device) if out is None else out
-        _check(self.lib.cat_ckks_multiply(self.h, self._p(x), self._p(y), self._p(out), L, b, self._stream()))
+        _check(self.lib.cat_ckks_multiply(self.h, self._p(x, (b, 2, L, self.n)), self._p(y, (b, 2, L, self.n)),
+                                        self._p(out, (b, 3, L, self.n)), L, b, self._stream()))
         return out
 
     def bgv_multiply(self, x, y, out=None):
         """x, y: [batch, 2, L, N] NTT form -> [batch, 3, L, N] (evaluator.cpp:710-841)"""
         b, _, L, _ = x.shape
         out = torch.empty((b, 3, L, self.n), dtype=torch.int64, device=x.device) if out is None else out
-        _check(self.lib.cat_bgv_multiply(self.h, self._p(x), self._p(y), self._p(out), L, b, self._stream()))
+        _check(self.lib.cat_bgv_multiply(self.h, self._p(x, (b, 2, L, self.n)), self._p(y, (b, 2, L, self.n)),
+                                        self._p(out, (b, 3, L, self.n)), L, b, self._stream()))
         return out
 
     def bgv_inv_q_last_mod_t(self, L: int) -> int:
@@ -174,7 +190,8 @@ class Context:
         """x: [batch, 2, L, N] -> [batch, 3, L, N]"""
         b, _, L, _ = x.shape
         out = torch.empty((b, 3, L, self.n), dtype=torch.int64, device=x.device) if out is None else out
-        _check(self.lib.cat_ckks_square(self.h, self._p(x), self._p(out), L, b, self._stream()))
+        _check(self.lib.cat_ckks_square(self.h, self._p(x, (b, 2, L, self.n)), self._p(out, (b, 3, L, self.n)), L, b,
+                                        self._stream()))
         return out
 
     def _plain(self, fn, ct, plain, out):
@@ -182,8 +199,9 @@ class Context:
         b, size, L, _ = ct.shape
         out = torch.empty_like(ct) if out is None else out
         stride = 0 if plain.dim() == 2 else L * self.n
-        assert plain.shape[-2] == L and (plain.dim() == 2 or plain.shape[0] == b)
-        _check(fn(self.h, self._p(ct), self._p(plain), stride, self._p(out), L, size, b, self._stream()))
+        if plain.shape[-2] != L or not (plain.dim() == 2 or (plain.dim() == 3 and plain.shape[0] == b)):
+            raise ValueError("plain is [L, N] (shared) or [batch, L, N]")
+        _check(fn(self.h, self._p(ct), self._p(plain), stride, self._p(out, ct.shape), L, size, b, self._stream()))
         return out
 
     def multiply_plain_ntt(self, ct, plain, out=None):
@@ -198,7 +216,8 @@ class Context:
     def bfv_multiply(self, x, y, out=None):
         b, _, L, _ = x.shape
         out = torch.empty((b, 3, L, self.n), dtype=torch.int64, device=x.device) if out is None else out
-        _check(self.lib.cat_bfv_multiply(self.h, self._p(x), self._p(y), self._p(out), L, b, self._stream()))
+        _check(self.lib.cat_bfv_multiply(self.h, self._p(x, (b, 2, L, self.n)), self._p(y, (b, 2, L, self.n)),
+                                        self._p(out, (b, 3, L, self.n)), L, b, self._stream()))
         return out
 
     # -- BEHZ pieces (util/rns.cpp:903-1131), one level with L limbs ------------------------------------
@@ -209,7 +228,8 @@ class Context:
         return [int(out[i]) for i in range(n)]
 
     def _piece(self, fn, x, L, in_limbs, out_limbs):
-        assert x.shape[-2] == in_limbs, (x.shape, in_limbs)
+        if x.shape[-2] != in_limbs:
+            raise ValueError(f"expected {in_limbs} limbs, got {x.shape[-2]}")
         npoly = x.numel() // (in_limbs * self.n)
         out = torch.empty(tuple(x.shape[:-2]) + (out_limbs, self.n), dtype=torch.int64, device=x.device)
         _check(fn(self.h, self._p(x), self._p(out), L, npoly, self._stream()))
@@ -235,7 +255,8 @@ class Context:
     def switch_key(self, enc, target, key):
         """enc: [batch, 2, L, N] in place; target: [batch, L, N]; key: [k-1, 2, k, N]"""
         b, _, L, _ = enc.shape
-        _check(self.lib.cat_switch_key(self.h, self._p(enc), self._p(target), self._p(key), L, b, self._stream()))
+        _check(self.lib.cat_switch_key(self.h, self._p(enc, (b, 2, L, self.n)), self._p(target, (b, L, self.n)),
+                                       self._key(key), L, b, self._stream()))
         return enc
 
     def key_broadcast(self, key, comm=None, root=0, bucket_words=0):
@@ -248,20 +269,21 @@ class Context:
     def relinearize(self, ct3, key):
         """ct3: [batch, 3, L, N]; returns a view of the first two polys (updated in place)."""
         b, _, L, _ = ct3.shape
-        _check(self.lib.cat_relinearize(self.h, self._p(ct3), self._p(key), L, b, self._stream()))
+        _check(self.lib.cat_relinearize(self.h, self._p(ct3, (b, 3, L, self.n)), self._key(key), L, b, self._stream()))
         return ct3[:, :2]
 
     def relinearize_rescale(self, ct3, key, out=None):
         """ct3: [batch, 3, L, N] (scratch afterwards) -> [batch, 2, L-1, N] = rescale(relinearize(ct3))"""
         b, _, L, _ = ct3.shape
         out = torch.empty((b, 2, L - 1, self.n), dtype=torch.int64, device=ct3.device) if out is None else out
-        _check(self.lib.cat_relinearize_rescale(self.h, self._p(ct3), self._p(key), self._p(out), L, b, self._stream()))
+        _check(self.lib.cat_relinearize_rescale(self.h, self._p(ct3, (b, 3, L, self.n)), self._key(key),
+                                                self._p(out, (b, 2, L - 1, self.n)), L, b, self._stream()))
         return out
 
     def rescale(self, ct, out=None):
         b, size, L, _ = ct.shape
         out = torch.empty((b, size, L - 1, self.n), dtype=torch.int64, device=ct.device) if out is None else out
-        _check(self.lib.cat_rescale(self.h, self._p(ct), self._p(out), L, size, b, self._stream()))
+        _check(self.lib.cat_rescale(self.h, self._p(ct), self._p(out, (b, size, L - 1, self.n)), L, size, b, self._stream()))
         return out
 
     NOALLOC_SCRATCH_BYTES = 64 << 20  # CAT_NOALLOC_SCRATCH_BYTES (include/cat_amd.h)
@@ -269,12 +291,15 @@ class Context:
     def rescale_noalloc(self, ct, out):
         """cat_rescale_noalloc: `out` is required (this path allocates nothing, torch included)."""
         b, size, L, _ = ct.shape
-        _check(self.lib.cat_rescale_noalloc(self.h, self._p(ct), self._p(out), L, size, b, self._stream()))
+        _check(self.lib.cat_rescale_noalloc(self.h, self._p(ct), self._p(out, (b, size, L - 1, self.n)), L, size, b,
+                                            self._stream()))
         return out
 
     def rescale_strided(self, ct, size, out):
         """ct: [batch, S, L, N] of which the first `size` polys are the ciphertext (stride S*L*N)."""
         b, S, L, _ = ct.shape
+        if out.dim() != 4 or out.shape[0] != b or out.shape[1] < size or out.shape[2] != L - 1 or size > S:
+            raise ValueError("out is [batch, >= size, L-1, N]")
         _check(self.lib.cat_rescale_strided(self.h, self._p(ct), S * L * self.n, self._p(out),
                                             out.shape[1] * (L - 1) * self.n, L, size, b, self._stream()))
         return out
@@ -282,6 +307,8 @@ class Context:
     def mod_drop(self, ct, out=None):
         b, size, L, _ = ct.shape
         out = torch.empty((b, size, L - 1, self.n), dtype=torch.int64, device=ct.device) if out is None else out
+        if out.numel() < b * size * (L - 1) * self.n:
+            raise ValueError("out is too small")
         _check(self.lib.cat_mod_drop(self.h, self._p(ct), self._p(out), L, size, b, self._stream()))
         return out
 
@@ -289,27 +316,29 @@ class Context:
         out = torch.empty_like(x) if out is None else out
         nl = x.shape[-2]
         npoly = x.numel() // (nl * self.n)
-        _check(self.lib.cat_apply_galois_ntt(self.h, self._p(x), self._p(out), elt, nl, npoly, self._stream()))
+        _check(self.lib.cat_apply_galois_ntt(self.h, self._p(x), self._p(out, x.shape), elt, nl, npoly, self._stream()))
         return out
 
     def apply_galois(self, x, elt, out=None, limb_ids=None):
         out = torch.empty_like(x) if out is None else out
         nl = x.shape[-2]
         npoly = x.numel() // (nl * self.n)
-        _check(self.lib.cat_apply_galois(self.h, self._p(x), self._p(out), elt, self._ids(limb_ids), nl, npoly,
+        _check(self.lib.cat_apply_galois(self.h, self._p(x), self._p(out, x.shape), elt, self._ids(limb_ids), nl, npoly,
                                          self._stream()))
         return out
 
     def apply_galois_inplace(self, ct, elt, key):
         b, _, L, _ = ct.shape
-        _check(self.lib.cat_apply_galois_inplace(self.h, self._p(ct), elt, self._p(key), L, b, self._stream()))
+        _check(self.lib.cat_apply_galois_inplace(self.h, self._p(ct, (b, 2, L, self.n)), elt, self._key(key), L, b,
+                                                 self._stream()))
         return ct
 
     def apply_galois_rescale(self, ct, elt, key, out=None):
         """ct: [batch, 2, L, N] (scratch afterwards) -> [batch, 2, L-1, N] = rescale(apply_galois(ct))"""
         b, _, L, _ = ct.shape
         out = torch.empty((b, 2, L - 1, self.n), dtype=torch.int64, device=ct.device) if out is None else out
-        _check(self.lib.cat_apply_galois_rescale(self.h, self._p(ct), elt, self._p(key), self._p(out), L, b, self._stream()))
+        _check(self.lib.cat_apply_galois_rescale(self.h, self._p(ct, (b, 2, L, self.n)), elt, self._key(key),
+                                                 self._p(out, (b, 2, L - 1, self.n)), L, b, self._stream()))
         return out
 
     def rotate_vector(self, ct, step, key):

@@ -558,6 +558,8 @@ cat_status cat_fastbconv_m_tilde(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d
         return st;
     if (n_polys && (!d_in || !d_out))
         return fail(CAT_ERR_INVALID_ARG, "input");
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 15)
+        return fail(CAT_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     return conv_q_to_Bsk(ctx, *lv, (const u64 *)d_in, (u64)L * ctx->n, (u64 *)d_out, (u64)(lv->Bsk + 1) * ctx->n,
                          ops_at(*lv, lv->o_mtilde_q), true, n_polys, (hipStream_t)s);
 }
@@ -570,6 +572,8 @@ cat_status cat_sm_mrq(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint3
         return st;
     if (n_polys && (!d_in || !d_out))
         return fail(CAT_ERR_INVALID_ARG, "input");
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 15)
+        return fail(CAT_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     return run_sm_mrq(ctx, *lv, (const u64 *)d_in, (u64)(lv->Bsk + 1) * ctx->n, (u64 *)d_out, (u64)lv->Bsk * ctx->n,
                       n_polys, (hipStream_t)s);
 }
@@ -583,6 +587,8 @@ cat_status cat_fast_floor(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, u
         return st;
     if (n_polys && (!d_in || !d_out))
         return fail(CAT_ERR_INVALID_ARG, "input");
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 15)
+        return fail(CAT_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     const u64 stride = (u64)(L + lv->Bsk) * ctx->n;
     return run_fast_floor(ctx, *lv, (const u64 *)d_in, stride, (const u64 *)d_in + (u64)L * ctx->n, stride,
                           (u64 *)d_out, (u64)lv->Bsk * ctx->n, false, n_polys, (hipStream_t)s);
@@ -597,6 +603,8 @@ cat_status cat_fastbconv_sk(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out,
         return st;
     if (n_polys && (!d_in || !d_out))
         return fail(CAT_ERR_INVALID_ARG, "input");
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 15)
+        return fail(CAT_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     u64 *conv = (u64 *)workspace(ctx, (size_t)n_polys * (L + 1) * ctx->n * sizeof(u64));
     if (!conv)
         return CAT_ERR_NOMEM;
@@ -615,6 +623,8 @@ cat_status cat_bfv_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d
         return CAT_OK;
     if (!d_x || !d_y || !d_out)
         return fail(CAT_ERR_INVALID_ARG, "encrypted1 or encrypted2 is not valid");
+    if (((uintptr_t)d_x | (uintptr_t)d_y | (uintptr_t)d_out) & 15)
+        return fail(CAT_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     if (d_out == d_x || d_out == d_y)
         return fail(CAT_ERR_INVALID_ARG, "destination must not alias the inputs");
     const BfvLevel &lv = *lvp;

@@ -3,6 +3,7 @@
 #include "context.hpp"
 
 #include <cstring>
+#include <initializer_list>
 #include <mutex>
 #include <new>
 
@@ -125,6 +126,15 @@ namespace
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess)
             return hip_fail(e, "hipSetDevice");
+        return CAT_OK;
+    }
+
+    // the kernels move 16 bytes per lane (ulonglong2): every device operand must be 16-byte aligned
+    cat_status aligned16(std::initializer_list<const void *> ptrs)
+    {
+        for (const void *p : ptrs)
+            if ((reinterpret_cast<uintptr_t>(p) & 15) != 0)
+                return fail(CAT_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
         return CAT_OK;
     }
 
@@ -358,6 +368,32 @@ cat_status cat_ctx_reserve(cat_ctx *ctx, size_t bytes)
     return workspace(ctx, bytes) || bytes == 0 ? CAT_OK : CAT_ERR_NOMEM;
 }
 
+size_t cat_ctx_workspace_need(const cat_ctx *ctx, uint32_t batch)
+{
+    // the largest request any entry point makes for `batch` ciphertexts (size <= 3) at any level of this context;
+    // keep in step with launch_switch_key / galois_inplace / launch_rescale / cat_mod_drop / cat_bfv_multiply
+    if (!ctx || batch == 0)
+        return 0;
+    const size_t N = ctx->n, b = batch, k = ctx->k;
+    const size_t L = k > 1 ? k - 1 : 1;
+    size_t words = 0;
+    if (k > 1 && ctx->scheme != CAT_SCHEME_NONE)
+    {
+        const size_t ks = b * (L + (L + 1) * L + 2 * (L + 1) + 2 * L + 4) * N;
+        words = ks + b * 2 * L * N; // apply_galois keeps the permuted copy behind the key-switch region
+    }
+    const size_t polys = b * 3;
+    const size_t rescale = polys * N + 2 * polys * (k - 1) * N; // level k
+    words = rescale > words ? rescale : words;
+    if (ctx->scheme == CAT_SCHEME_BFV)
+    {
+        const size_t Bsk = L + 2; // |B| = L + 1 at the largest level, plus m_sk
+        const size_t bfv = b * (4 * L + 4 * Bsk + 4 * (Bsk + 1) + 3 * L + 3 * Bsk + 3 * Bsk) * N;
+        words = bfv > words ? bfv : words;
+    }
+    return words * sizeof(u64);
+}
+
 size_t cat_ctx_workspace_bytes(const cat_ctx *ctx)
 {
     return ctx ? ctx->ws_bytes : 0;
@@ -443,6 +479,8 @@ static cat_status ntt_common(cat_ctx *ctx, bool fwd, uint64_t *d_data, const uin
         return st;
     if (!d_data && n_limbs && n_polys)
         return fail(CAT_ERR_INVALID_ARG, "operand");
+    if ((st = aligned16({ d_data })) != CAT_OK)
+        return st;
     LimbMap map;
     st = make_map(ctx, limb_ids, n_limbs, map);
     if (st != CAT_OK)
@@ -478,6 +516,8 @@ static cat_status ew_common(cat_ctx *ctx, int op, const uint64_t *a, const uint6
         if (!out)
             return fail(CAT_ERR_INVALID_ARG, "result");
     }
+    if ((st = aligned16({ a, b, out })) != CAT_OK)
+        return st;
     LimbMap map;
     st = make_map(ctx, limb_ids, n_limbs, map);
     if (st != CAT_OK)
@@ -525,6 +565,8 @@ static cat_status scalar_common(cat_ctx *ctx, int op, const uint64_t *a, const u
         return fail(CAT_ERR_INVALID_ARG, a ? "result" : "poly");
     if (nl && !scalars)
         return fail(CAT_ERR_INVALID_ARG, "scalar");
+    if ((st = aligned16({ a, out })) != CAT_OK)
+        return st;
     LimbMap map;
     st = make_map(ctx, ids, nl, map);
     if (st != CAT_OK)
@@ -572,6 +614,8 @@ cat_status cat_ckks_multiply(cat_ctx *ctx, const uint64_t *x, const uint64_t *y,
         return fail(CAT_ERR_INVALID_ARG, "encrypted1 or encrypted2 is not valid");
     if (out == x || out == y)
         return fail(CAT_ERR_INVALID_ARG, "destination must not alias the inputs");
+    if ((st = aligned16({ x, y, out })) != CAT_OK)
+        return st;
     return launch_ckks_tensor(ctx, (const u64 *)x, (const u64 *)y, (u64 *)out, L, batch, (hipStream_t)s);
 }
 
@@ -600,6 +644,8 @@ cat_status cat_ckks_square(cat_ctx *ctx, const uint64_t *x, uint64_t *out, uint3
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
     if (out == x)
         return fail(CAT_ERR_INVALID_ARG, "destination must not alias the input");
+    if ((st = aligned16({ x, out })) != CAT_OK)
+        return st;
     return launch_ckks_square(ctx, (const u64 *)x, (u64 *)out, L, batch, (hipStream_t)s);
 }
 
@@ -619,6 +665,8 @@ static cat_status plain_common(cat_ctx *ctx, int op, const uint64_t *ct, const u
         return fail(CAT_ERR_INVALID_ARG, "plain is not valid for encryption parameters");
     if (plain_stride != 0 && (plain_stride < (size_t)L * ctx->n || (plain_stride & 1)))
         return fail(CAT_ERR_INVALID_ARG, "stride");
+    if ((st = aligned16({ ct, plain, out })) != CAT_OK)
+        return st;
     return launch_plain(ctx, op, (const u64 *)ct, (const u64 *)plain, plain_stride, (u64 *)out, L, size, batch,
                         (hipStream_t)s);
 }
@@ -661,6 +709,8 @@ cat_status cat_switch_key(cat_ctx *ctx, uint64_t *enc, const uint64_t *target, c
     // has at most CAT_MAX_MODULI = 64 primes, so L <= 63 here, and the check says so explicitly
     if (L > CAT_MAX_KEYSWITCH_LIMBS)
         return fail(CAT_ERR_LOGIC, "invalid parameters");
+    if ((st = aligned16({ enc, target, key })) != CAT_OK)
+        return st;
     if (batch == 0)
         return CAT_OK;
     return launch_switch_key(ctx, (u64 *)enc, (const u64 *)target, (const u64 *)key, L, batch, (size_t)2 * L * ctx->n,
@@ -680,6 +730,8 @@ cat_status cat_relinearize(cat_ctx *ctx, uint64_t *ct3, const uint64_t *key, uin
         return fail(CAT_ERR_LOGIC, "keyswitching is not supported by the context");
     if (L == 0 || L >= ctx->k || L > CAT_MAX_KEYSWITCH_LIMBS)
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if ((st = aligned16({ ct3, key })) != CAT_OK)
+        return st;
     if (batch == 0)
         return CAT_OK;
     // the target of ciphertext b is its own third polynomial (stride 3*L*N for both)
@@ -704,6 +756,8 @@ cat_status cat_relinearize_rescale(cat_ctx *ctx, uint64_t *ct3, const uint64_t *
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
     if (L < 2)
         return fail(CAT_ERR_INVALID_ARG, "end of modulus switching chain reached");
+    if ((st = aligned16({ ct3, key, out })) != CAT_OK)
+        return st;
     if (batch == 0)
         return CAT_OK;
     const size_t N = ctx->n, stride = (size_t)3 * L * N, out_stride = (size_t)2 * (L - 1) * N;
@@ -731,6 +785,8 @@ cat_status cat_rescale(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t
         return st;
     if (size * batch && (!in || !out))
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if ((st = aligned16({ in, out })) != CAT_OK)
+        return st;
     return launch_rescale(ctx, (const u64 *)in, (u64 *)out, L, size, batch, (size_t)size * L * ctx->n,
                           (size_t)size * (L - 1) * ctx->n, (hipStream_t)s);
 }
@@ -747,6 +803,8 @@ cat_status cat_rescale_noalloc(cat_ctx *ctx, const uint64_t *in, uint64_t *out, 
         return st;
     if (size * batch && (!in || !out))
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if ((st = aligned16({ in, out })) != CAT_OK)
+        return st;
     void *scratch = noalloc_scratch(ctx->device);
     if (!scratch)
         return fail(CAT_ERR_LOGIC, "no static scratch buffer on this device");
@@ -768,6 +826,8 @@ cat_status cat_rescale_strided(cat_ctx *ctx, const uint64_t *in, size_t in_strid
         return st;
     if (size * batch && (!in || !out))
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if ((st = aligned16({ in, out })) != CAT_OK)
+        return st;
     if (in_stride < (size_t)size * L * ctx->n || out_stride < (size_t)size * (L - 1) * ctx->n || (in_stride & 1) ||
         (out_stride & 1))
         return fail(CAT_ERR_INVALID_ARG, "stride");
@@ -785,6 +845,8 @@ cat_status cat_mod_drop(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_
     const uint32_t polys = size * batch;
     if (polys && (!in || !out))
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if ((st = aligned16({ in, out })) != CAT_OK)
+        return st;
     if (in == out && polys > 1)
     {
         const size_t bytes = (size_t)polys * (L - 1) * ctx->n * sizeof(u64);
@@ -827,6 +889,8 @@ static cat_status galois_check(cat_ctx *ctx, const uint64_t *in, uint64_t *out, 
         return fail(CAT_ERR_INVALID_ARG, "result");
     if (in == out)
         return fail(CAT_ERR_INVALID_ARG, "result cannot point to the same value as operand");
+    if (aligned16({ in, out }) != CAT_OK)
+        return CAT_ERR_INVALID_ARG;
     if (!(elt & 1) || elt >= 2 * (uint64_t)ctx->n)
         return fail(CAT_ERR_INVALID_ARG, "Galois element is not valid");
     return CAT_OK;
@@ -897,6 +961,8 @@ static cat_status galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, const
         return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
     if (!key)
         return fail(CAT_ERR_INVALID_ARG, "Galois key not present");
+    if ((st = aligned16({ ct, key, rescale_out })) != CAT_OK)
+        return st;
     if (!(elt & 1) || elt >= 2 * (uint64_t)ctx->n)
         return fail(CAT_ERR_INVALID_ARG, "Galois element is not valid");
     if (batch == 0)

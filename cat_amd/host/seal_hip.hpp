@@ -24,6 +24,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstdint>
+#include <initializer_list>
+#include <limits>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -31,6 +33,7 @@
 #include <utility>
 #include <vector>
 
+#include "seal_hip_modulus.hpp"
 #include "seal_hip_serialization.hpp" // brings seal_hip_random.hpp
 
 namespace seal
@@ -64,6 +67,12 @@ namespace seal
                 throw std::runtime_error(cat_last_error());
             }
         }
+        // util::are_close<double> (util/common.h:568-574), what are_same_scale compares with (evaluator.cpp:24-26)
+        inline bool are_close(double a, double b) noexcept
+        {
+            const double scale = std::max(std::max(std::fabs(a), std::fabs(b)), 1.0);
+            return std::fabs(a - b) < std::numeric_limits<double>::epsilon() * scale;
+        }
     } // namespace detail
 
     class EncryptionParameters
@@ -75,13 +84,32 @@ namespace seal
         {
             n_ = n;
         }
+        // encryptionparams.cuh set_coeff_modulus(const std::vector<Modulus> &); the facade also takes plain words
+        void set_coeff_modulus(const std::vector<Modulus> &q)
+        {
+            qm_ = q;
+            q_.clear();
+            for (const Modulus &m : q)
+                q_.push_back(m.value());
+        }
         void set_coeff_modulus(const std::vector<std::uint64_t> &q)
         {
-            q_ = q;
+            std::vector<Modulus> m;
+            for (std::uint64_t v : q)
+                m.emplace_back(v); // throws like Modulus::set_value on values above 61 bits
+            set_coeff_modulus(m);
+        }
+        void set_coeff_modulus(std::initializer_list<std::uint64_t> q)
+        {
+            set_coeff_modulus(std::vector<std::uint64_t>(q));
+        }
+        void set_plain_modulus(const Modulus &t)
+        {
+            t_ = t;
         }
         void set_plain_modulus(std::uint64_t t)
         {
-            t_ = t;
+            t_ = Modulus(t);
         }
         scheme_type scheme() const noexcept
         {
@@ -91,11 +119,16 @@ namespace seal
         {
             return n_;
         }
-        const std::vector<std::uint64_t> &coeff_modulus() const noexcept
+        const std::vector<Modulus> &coeff_modulus() const noexcept
+        {
+            return qm_;
+        }
+        // the primes as plain words, the form the C ABI takes (not in the reference)
+        const std::vector<std::uint64_t> &coeff_modulus_words() const noexcept
         {
             return q_;
         }
-        std::uint64_t plain_modulus() const noexcept
+        const Modulus &plain_modulus() const noexcept
         {
             return t_;
         }
@@ -113,7 +146,8 @@ namespace seal
         scheme_type scheme_;
         std::size_t n_ = 0;
         std::vector<std::uint64_t> q_;
-        std::uint64_t t_ = 0;
+        std::vector<Modulus> qm_;
+        Modulus t_;
         std::shared_ptr<UniformRandomGeneratorFactory> random_generator_;
     };
 
@@ -132,9 +166,14 @@ namespace seal
             if (n == 0 || (std::size_t(1) << log_n) != n)
                 throw std::invalid_argument("poly_modulus_degree is invalid");
             cat_ctx *h = nullptr;
-            detail::check(cat_ctx_create(log_n, parms.coeff_modulus().data(), (std::uint32_t)parms.coeff_modulus().size(),
-                                         (int)parms.scheme(), parms.plain_modulus(), device, &h));
+            detail::check(cat_ctx_create(log_n, parms.coeff_modulus_words().data(),
+                                         (std::uint32_t)parms.coeff_modulus_words().size(), (int)parms.scheme(),
+                                         parms.plain_modulus().value(), device, &h));
             h_.reset(h, [](cat_ctx *p) { cat_ctx_destroy(p); });
+            // temporaries of every operation on one ciphertext at any level, allocated once here so that no Evaluator
+            // call ever synchronises or allocates on its way (cat_ctx_workspace_need; larger batches through the C ABI
+            // grow the block on first use, or call cat_ctx_reserve themselves)
+            detail::check(cat_ctx_reserve(h, cat_ctx_workspace_need(h, 1)));
         }
         cat_ctx *handle() const noexcept
         {
@@ -150,7 +189,7 @@ namespace seal
         }
         std::size_t key_modulus_size() const noexcept
         {
-            return parms_.coeff_modulus().size();
+            return parms_.coeff_modulus_words().size();
         }
         std::size_t first_level_size() const noexcept
         {
@@ -168,7 +207,8 @@ namespace seal
             if (coeff_modulus_size == 0 || coeff_modulus_size > key_modulus_size())
                 throw std::invalid_argument("parms_id is not valid for encryption parameters");
             return util::compute_parms_id((std::uint8_t)parms_.scheme(), parms_.poly_modulus_degree(),
-                                          parms_.coeff_modulus().data(), coeff_modulus_size, parms_.plain_modulus());
+                                          parms_.coeff_modulus_words().data(), coeff_modulus_size,
+                                          parms_.plain_modulus().value());
         }
         parms_id_type key_parms_id() const
         {
@@ -199,6 +239,11 @@ namespace seal
         Ciphertext(const SEALContext &context, std::size_t coeff_modulus_size, std::size_t size = 2)
         {
             resize(context, coeff_modulus_size, size);
+        }
+        // ciphertext.cuh:60-120: Ciphertext(context, parms_id [, size_capacity]) -- an empty ciphertext of that level
+        Ciphertext(const SEALContext &context, const parms_id_type &parms_id, std::size_t size = 2)
+        {
+            resize(context, parms_id, size);
         }
         Ciphertext(const Ciphertext &o)
         {
@@ -284,6 +329,13 @@ namespace seal
             }
             size_ = size;
             L_ = coeff_modulus_size;
+        }
+        void resize(const SEALContext &context, const parms_id_type &parms_id, std::size_t size)
+        {
+            const std::size_t L = context.level_of(parms_id);
+            if (!L)
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            resize(context, L, size);
         }
         void resize(std::size_t size)
         {
@@ -441,7 +493,7 @@ namespace seal
                         if (!prng)
                             throw std::logic_error("unsupported prng_type");
                         data.resize(total);
-                        const auto &q = context.parms().coeff_modulus();
+                        const auto &q = context.parms().coeff_modulus_words();
                         util::sample_poly_uniform(prng, std::vector<std::uint64_t>(q.begin(), q.begin() + (std::ptrdiff_t)L),
                                                   (std::size_t)n64, data.data() + L * n64);
                     }
@@ -1479,7 +1531,7 @@ namespace seal
                 throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
             if (a.is_ntt_form() != b.is_ntt_form())
                 throw std::invalid_argument("NTT form mismatch");
-            if (a.scale() != b.scale())
+            if (!detail::are_close(a.scale(), b.scale()))
                 throw std::invalid_argument("scale mismatch");
         }
         // balance_correction_factors (evaluator.cpp:56-118): {new factor, e1, e2} with e1 f1 = e2 f2 (mod t) and
@@ -1646,7 +1698,7 @@ namespace seal
                 throw std::invalid_argument("NTT form mismatch");
             if (encrypted.coeff_modulus_size() != plain.coeff_modulus_size())
                 throw std::invalid_argument("encrypted and plain parameter mismatch");
-            if (encrypted.scale() != plain.scale())
+            if (!detail::are_close(encrypted.scale(), plain.scale()))
                 throw std::invalid_argument("scale mismatch");
             auto fn = sub ? cat_sub_plain : cat_add_plain;
             detail::check(fn(h(), encrypted.d_data(), plain.d_data(), 0, encrypted.d_data(),

@@ -252,7 +252,7 @@ namespace seal
 
         inline std::vector<std::uint64_t> level_primes(const SEALContext &context, std::size_t L)
         {
-            const auto &q = context.parms().coeff_modulus();
+            const auto &q = context.parms().coeff_modulus_words();
             if (L == 0 || L > q.size())
                 throw std::invalid_argument("parms_id is not valid for encryption parameters");
             return std::vector<std::uint64_t>(q.begin(), q.begin() + (std::ptrdiff_t)L);
@@ -314,7 +314,7 @@ namespace seal
                     const std::vector<std::uint64_t> data = util::dynarray_load(s, words);
                     if (data.size() != words)
                         throw std::logic_error("SecretKey data is invalid");
-                    const auto &q = context.parms().coeff_modulus();
+                    const auto &q = context.parms().coeff_modulus_words();
                     for (std::size_t j = 0; j < q.size(); ++j)
                         for (std::size_t i = 0; i < context.poly_modulus_degree(); ++i)
                             if (data[j * context.poly_modulus_degree() + i] >= q[j])
@@ -554,7 +554,7 @@ namespace seal
         {
             const std::size_t k = context_.key_modulus_size(), n = context_.poly_modulus_degree();
             std::vector<std::uint64_t> s(k * n);
-            util::sample_poly_ternary(context_.parms().random_generator()->create(), context_.parms().coeff_modulus(), n, s.data());
+            util::sample_poly_ternary(context_.parms().random_generator()->create(), context_.parms().coeff_modulus_words(), n, s.data());
             secret_key_.data_ = std::make_shared<detail::DeviceWords>(context_.handle(), s);
             detail::check(cat_ntt_forward(context_.handle(), secret_key_.data_->get(), nullptr, (std::uint32_t)k, 1, 0, nullptr));
             detail::check(cat_stream_sync(context_.handle(), nullptr));
@@ -569,7 +569,7 @@ namespace seal
             cat_ctx *h = context_.handle();
             const std::size_t k = context_.key_modulus_size(), n = context_.poly_modulus_degree();
             const std::size_t decomp_mod_count = context_.first_level_size();
-            const auto &key_modulus = context_.parms().coeff_modulus();
+            const auto &key_modulus = context_.parms().coeff_modulus_words();
             detail::DeviceWords temp(h, n);
             for (std::size_t J = 0; J < decomp_mod_count; ++J)
             {

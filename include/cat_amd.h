@@ -8,7 +8,8 @@
  * these symbols behind the reference's class and function names.
  *
  * Conventions
- *  - All pointers named d_* are DEVICE pointers (hipMalloc'ed or torch-owned), 8-byte aligned.
+ *  - All pointers named d_* are DEVICE pointers (hipMalloc'ed or torch-owned), 16-byte aligned (the kernels move
+ *    16 bytes per lane; a misaligned operand is refused with CAT_ERR_INVALID_ARG).
  *  - Polynomial layout is the reference's: poly[limb][coeff], limbs contiguous, N words each
  *    (RNSIter, util/iterator.h:951); a ciphertext is size x L x N words (ciphertext.cuh:423-434);
  *    a batch is `batch` such objects back to back.
@@ -68,6 +69,10 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
 cat_status cat_ctx_destroy(cat_ctx *ctx);
 cat_status cat_ctx_reserve(cat_ctx *ctx, size_t workspace_bytes);
 size_t cat_ctx_workspace_bytes(const cat_ctx *ctx);
+/* Bytes of workspace the largest call on `batch` ciphertexts (size <= 3, any level, any entry point) needs: reserving
+ * that much once (cat_ctx_reserve) means no later call synchronises, frees or allocates.  The C++ facade does so for
+ * batch 1 when it builds a SEALContext. */
+size_t cat_ctx_workspace_need(const cat_ctx *ctx, uint32_t batch);
 uint32_t cat_ctx_log_n(const cat_ctx *ctx);
 uint32_t cat_ctx_n_primes(const cat_ctx *ctx);
 /* NTTTables::get_root() (util/ntt.h:101): the minimal primitive 2N-th root used for prime i */

@@ -1007,11 +1007,147 @@ static void test_plain_modes(const std::string &dir, scheme_type scheme)
     f.write(reinterpret_cast<const char *>(got.data()), (std::streamsize)(got.size() * 8));
 }
 
+
+// A caller written the way the reference's examples set a CKKS circuit up (native/examples/4_ckks_basics.cpp:60-110,
+// minus the encoder, which is out of scope): Modulus / CoeffModulus::Create / set_coeff_modulus(vector<Modulus>),
+// KeyGenerator, Encryptor, Evaluator, Ciphertext(context, parms_id).  The words are checked against the oracle.
+static void test_reference_idiom()
+{
+    // Modulus: const_ratio = floor(2^128 / value) and the remainder (modulus.cpp:87-98), the limits of set_value
+    {
+        Modulus m(0xffffffffffc0001ULL);
+        so_modulus om;
+        so_modulus_init(&om, m.value());
+        EXPECT(m.bit_count() == 60 && m.is_prime() && !m.is_zero() && m.uint64_count() == 1);
+        EXPECT(m.const_ratio()[0] == om.ratio[0] && m.const_ratio()[1] == om.ratio[1]);
+        const unsigned __int128 back = (((unsigned __int128)m.const_ratio()[1] << 64) | m.const_ratio()[0]) * m.value() + m.const_ratio()[2];
+        EXPECT(back == 0); // = 2^128 modulo 2^128
+        EXPECT(m.reduce(m.value() + 5) == 5);
+        EXPECT(throws<std::invalid_argument>([] { Modulus bad(std::uint64_t(1) << 61); }));
+        EXPECT(throws<std::invalid_argument>([] { Modulus bad(1); }));
+        EXPECT(Modulus().is_zero() && throws<std::logic_error>([] { Modulus().reduce(3); }));
+        EXPECT(!Modulus(15).is_prime());
+    }
+    // CoeffModulus (modulus.cpp:116-190, util/hestdparms.h, util/globals.cpp:24-70)
+    {
+        const int bits[4] = { 60, 40, 40, 60 };
+        vec ref(4);
+        EXPECT(so_coeff_modulus_create(8192, bits, 4, ref.data()) == 0);
+        const std::vector<Modulus> q = CoeffModulus::Create(8192, { 60, 40, 40, 60 });
+        EXPECT(q.size() == 4);
+        for (size_t i = 0; i < q.size(); ++i)
+            EXPECT(q[i].value() == ref[i]);
+        EXPECT(q[0] < q[3] && q[1] < q[2]); // equal sizes: smallest first
+        EXPECT(throws<std::invalid_argument>([] { CoeffModulus::Create(8192, { 61 }); }));
+        EXPECT(throws<std::invalid_argument>([] { CoeffModulus::Create(1000, { 40 }); }));
+        EXPECT(CoeffModulus::MaxBitCount(16384) == 438 && CoeffModulus::MaxBitCount(32768, sec_level_type::tc192) == 611 &&
+               CoeffModulus::MaxBitCount(3000) == 0);
+        for (size_t n : { size_t(4096), size_t(8192), size_t(16384), size_t(32768) })
+        {
+            vec d(32);
+            size_t cnt = 0;
+            EXPECT(so_bfv_default(n, d.data(), &cnt) == 0);
+            const std::vector<Modulus> b = CoeffModulus::BFVDefault(n);
+            EXPECT(b.size() == cnt);
+            int total = 0;
+            for (size_t i = 0; i < b.size() && i < cnt; ++i)
+            {
+                EXPECT(b[i].value() == d[i] && b[i].is_prime() && (b[i].value() - 1) % (2 * n) == 0);
+                total += b[i].bit_count();
+            }
+            EXPECT(total == CoeffModulus::MaxBitCount(n));
+        }
+        EXPECT(throws<std::invalid_argument>([] { CoeffModulus::BFVDefault(3000); }));
+        const Modulus t = PlainModulus::Batching(8192, 20);
+        EXPECT(t.bit_count() == 20 && t.is_prime() && (t.value() - 1) % 16384 == 0);
+        // BGV-style chain: every prime is also 1 modulo t (modulus.cpp:192-229)
+        for (const Modulus &m : CoeffModulus::Create(4096, Modulus(65537), { 40, 40, 41 }))
+            EXPECT(m.is_prime() && (m.value() - 1) % 8192 == 0 && (m.value() - 1) % 65537 == 0);
+    }
+
+    EncryptionParameters parms(scheme_type::ckks);
+    const size_t poly_modulus_degree = 8192;
+    parms.set_poly_modulus_degree(poly_modulus_degree);
+    parms.set_coeff_modulus(CoeffModulus::Create(poly_modulus_degree, { 60, 40, 40, 60 }));
+    const prng_seed_type seed = { 7, 7, 7, 7, 7, 7, 7, 7 };
+    parms.set_random_generator(std::make_shared<Blake2xbPRNGFactory>(seed));
+    EXPECT(parms.coeff_modulus().size() == 4 && parms.coeff_modulus()[0].bit_count() == 60 && parms.plain_modulus().is_zero());
+    SEALContext context(parms);
+    // the context pre-sized its workspace: nothing below allocates or synchronises inside an Evaluator call
+    const size_t reserved = cat_ctx_workspace_bytes(context.handle());
+    EXPECT(reserved >= cat_ctx_workspace_need(context.handle(), 1) && reserved > 0);
+
+    KeyGenerator keygen(context);
+    const SecretKey &secret_key = keygen.secret_key();
+    PublicKey public_key;
+    keygen.create_public_key(public_key);
+    RelinKeys relin_keys(context);
+    keygen.create_relin_keys(relin_keys);
+    GaloisKeys gal_keys(context);
+    keygen.create_galois_keys(std::vector<int>{ 1 }, gal_keys);
+    Encryptor encryptor(context, public_key);
+    Evaluator evaluator(context);
+    Decryptor decryptor(context, secret_key);
+
+    const double scale = std::pow(2.0, 40);
+    Ciphertext x1_encrypted, x2_encrypted;
+    encryptor.encrypt_zero(x1_encrypted);
+    encryptor.encrypt_zero(x2_encrypted);
+    x1_encrypted.scale() = scale;
+    // scales one ulp apart are "the same scale" (util::are_close, evaluator.cpp:24-26, 174)
+    x2_encrypted.scale() = std::nextafter(scale, 2 * scale);
+    EXPECT(x1_encrypted.parms_id() == context.first_parms_id() && x1_encrypted.coeff_modulus_size() == 3);
+    {
+        Ciphertext sum;
+        evaluator.add(x1_encrypted, x2_encrypted, sum);
+        x2_encrypted.scale() = scale * 1.5;
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.add(x1_encrypted, x2_encrypted, sum); }));
+        x2_encrypted.scale() = scale;
+    }
+
+    // Ciphertext(context, parms_id): an empty ciphertext of a named level (ciphertext.cuh:60-120)
+    Ciphertext destination(context, context.first_parms_id());
+    EXPECT(destination.size() == 2 && destination.coeff_modulus_size() == 3);
+    EXPECT(throws<std::invalid_argument>([&] { Ciphertext bad(context, parms_id_type{ 1, 2, 3, 4 }); }));
+
+    // x1 * x2, relinearize, rescale -- against the oracle on the same words and the same key
+    const size_t n = poly_modulus_degree, k = 4, L = 3;
+    vec primes;
+    for (const Modulus &m : parms.coeff_modulus())
+        primes.push_back(m.value());
+    so_context *oc = so_context_create(13, primes.data(), k, SO_SCHEME_CKKS, 0);
+    vec a = x1_encrypted.to_cpu(), b = x2_encrypted.to_cpu(), rk = relin_keys.key_to_cpu(0);
+    evaluator.multiply(x1_encrypted, x2_encrypted, destination);
+    evaluator.relinearize_inplace(destination, relin_keys);
+    evaluator.rescale_to_next_inplace(destination);
+    EXPECT(destination.size() == 2 && destination.coeff_modulus_size() == 2 && destination.parms_id() == context.parms_id(2));
+    EXPECT(std::fabs(destination.scale() - scale * scale / (double)primes[2]) < 1e-6 * destination.scale());
+    {
+        vec prod(3 * L * n);
+        std::copy(a.begin(), a.end(), prod.begin());
+        so_ckks_multiply(oc, L, prod.data(), b.data());
+        so_relinearize(oc, L, prod.data(), rk.data());
+        vec out(2 * (L - 1) * n);
+        so_mod_switch_scale_to_next(oc, L, prod.data(), 2, out.data());
+        EXPECT(destination.to_cpu() == out);
+    }
+    // the product of two encryptions of zero decrypts to noise far below the scale: |phase| < 2^60 at a 100-bit modulus
+    {
+        seal::detail::DeviceWords d_ph(context.handle(), 2 * n);
+        decryptor.dot_product_ct_sk_array(destination, d_ph.get());
+        EXPECT(d_ph.to_cpu().size() == 2 * n);
+    }
+    evaluator.rotate_vector_inplace(destination, 1, gal_keys);
+    EXPECT(cat_ctx_workspace_bytes(context.handle()) == reserved); // no call grew the workspace
+    so_context_destroy(oc);
+}
+
 int main(int argc, char **argv)
 {
     try
     {
         test_util_ntt_known_answers();
+        test_reference_idiom();
         test_ckks();
         test_bfv();
         test_bgv();

@@ -627,3 +627,35 @@ def test_square_and_plaintext_operands(cat, oracle):
     with pytest.raises(ValueError):
         ctx.ckks_square(alias, out=big)  # destination must not alias the input
     ctx.close()
+
+
+def test_python_plumbing_rejects_wrong_operands(cat, oracle):
+    """cat_amd/api.py raises ValueError (not assert) on operands the C ABI cannot check: dtype, contiguity, shape of
+    `out`, and the C ABI itself refuses device pointers that are not 16-byte aligned."""
+    import torch
+
+    n = 8
+    primes = oracle.get_primes(2 * n, 30, 2)
+    ctx = cat.Context(3, primes, cat.SCHEME_NONE)
+    x = torch.zeros((3, 2, n), dtype=torch.int64, device="cuda:0")
+    with pytest.raises(ValueError):
+        ctx.add(x, x, out=torch.zeros((3, 1, n), dtype=torch.int64, device="cuda:0"))
+    with pytest.raises(ValueError):
+        ctx.add(x, x.to(torch.int32))
+    with pytest.raises(ValueError):
+        ctx.add(x, x.cpu())
+    with pytest.raises(ValueError):
+        ctx.negate(x.transpose(0, 1))
+    with pytest.raises(ValueError):
+        ctx.add(x[..., :4], x[..., :4])
+    ctx.close()
+    # an odd word offset: N = 2 polynomials are 16 bytes, a view starting one word in is 8-byte aligned only
+    ctx = cat.Context(1, oracle.get_primes(4, 30, 1), cat.SCHEME_NONE)
+    flat = torch.zeros(10, dtype=torch.int64, device="cuda:0")
+    odd = flat[1:9].view(4, 1, 2)
+    with pytest.raises(ValueError, match="16-byte aligned"):
+        ctx.ntt_forward(odd)
+    with pytest.raises(ValueError, match="16-byte aligned"):
+        ctx.add(odd, odd)
+    ctx.ntt_forward(flat[2:10].view(4, 1, 2))
+    ctx.close()
