@@ -449,9 +449,12 @@ namespace
         const u32 n = 1u << log_n;
         const u32 first = inverse ? n - 256 + 1 : 0; // logical index of twl[0]
         const u32 e = threadIdx.x;
-        twl[e] = g.w0[first + e];
-        twl[256 + e] = g.w1[first + e];
-        twl[512 + e] = g.qq[first + e];
+        if (e < 256)
+        {
+            twl[e] = g.w0[first + e];
+            twl[256 + e] = g.w1[first + e];
+            twl[512 + e] = g.qq[first + e];
+        }
         Fast::Table t;
         t.w0 = twl - first;
         t.w1 = twl + 256 - first;
@@ -542,13 +545,13 @@ namespace
 
     // ---- forward, pass 1: columns ----------------------------------------------------------------------
     // one column tile (C columns x N1 rows) of the limb-polynomial w points at; tw = the staged column twiddles
-    template <class P, int LOGN1, bool DUAL>
+    template <class P, int LOGN1, bool DUAL, int TW = TILE_WORDS>
     __device__ __forceinline__ void fwd_cols_tile(const NttArgs &a, const Where &w, const typename P::Mod &m,
                                                   const typename P::Table &tw, u64 *lds)
     {
         constexpr int K1 = LOGN1 - 4;          // stages done in round 1
         constexpr int N1 = 1 << LOGN1;
-        constexpr int C = TILE_WORDS / N1;     // columns per workgroup
+        constexpr int C = TW / N1;             // columns per workgroup (TW / 16 threads)
         constexpr int SUB = 16 >> K1;          // consecutive rows per thread in round 1
         u64 *p = a.data + w.offset + w.tile * C;
         const Source in = source(a, w, w.tile * C);
@@ -599,17 +602,19 @@ namespace
             p[(tau * 16 + l) * ROW_LEN + c] = x[l];
     }
 
-    template <class P, int LOGN1, bool DUAL = false>
-    __global__ __launch_bounds__(256) void ntt_fwd_cols(NttArgs a)
+    // TW = words per workgroup tile (TW / 16 threads).  8192 at N = 2^16 makes the row segments a workgroup reads and
+    // writes 256 bytes long instead of 128: HBM gives that shape 5.04 TB/s against 4.77 (profiles/r02_access_shape_rates.txt)
+    template <class P, int LOGN1, bool DUAL = false, int TW = TILE_WORDS>
+    __global__ __launch_bounds__(TW / 16, 4) void ntt_fwd_cols(NttArgs a)
     {
-        __shared__ u64 lds[TILE_WORDS];
-        const Where w = locate(a, blockIdx.x, ROW_LEN / (TILE_WORDS >> LOGN1));
+        __shared__ u64 lds[TW];
+        const Where w = locate(a, blockIdx.x, ROW_LEN / (TW >> LOGN1));
         if (w.skip)
             return;
         const typename P::Mod m = P::mod(a.mods[w.mod]);
         __shared__ u64 twl[3 * 256];
         const typename P::Table tw = stage_col_twiddles(twl, P::table(a.tw, w.mod, a.log_n, false), a.log_n, false);
-        fwd_cols_tile<P, LOGN1, DUAL>(a, w, m, tw, lds);
+        fwd_cols_tile<P, LOGN1, DUAL, TW>(a, w, m, tw, lds);
     }
 
     // ---- forward, pass 2: rows (16 rows of 256 per workgroup) -------------------------------------------
@@ -927,14 +932,14 @@ namespace
     }
 
     // ---- inverse, pass 2: columns --------------------------------------------------------------------------
-    template <class P, int LOGN1>
-    __global__ __launch_bounds__(256, 4) void ntt_inv_cols(NttArgs a)
+    template <class P, int LOGN1, int TW = TILE_WORDS>
+    __global__ __launch_bounds__(TW / 16, 4) void ntt_inv_cols(NttArgs a)
     {
         constexpr int K1 = LOGN1 - 4;
         constexpr int N1 = 1 << LOGN1;
-        constexpr int C = TILE_WORDS / N1;
+        constexpr int C = TW / N1;
         constexpr int SUB = 16 >> K1;
-        __shared__ u64 lds[TILE_WORDS];
+        __shared__ u64 lds[TW];
 
         const u32 n = 1u << a.log_n;
         const Where w = locate(a, blockIdx.x, ROW_LEN / C);
@@ -1072,16 +1077,36 @@ namespace
         }
     }
 
+    // plain forward transforms of large batches (N = 2^16): column tiles twice as wide, 14.7 against 15.1 ms on
+    // BASELINE config 2 (same box); 1024-thread tiles of 64 columns measured slower (16.0 ms)
+    inline bool wide_tiles(const NttArgs &a)
+    {
+        return (u64)a.n_limbs * a.n_polys >= 2048;
+    }
+
     template <class P, int LOGN1>
     void launch_cols(bool fwd, const NttArgs &a, u32 blocks, hipStream_t s)
     {
         if (fwd && a.src2)
             hipLaunchKernelGGL((ntt_fwd_cols<P, LOGN1, true>), dim3(blocks), dim3(256), 0, s, a);
         else if (fwd)
+        {
+            if constexpr (LOGN1 == 8 && std::is_base_of<Fast, P>::value)
+            {
+                if (!a.src && wide_tiles(a))
+                {
+                    hipLaunchKernelGGL((ntt_fwd_cols<P, LOGN1, false, 2 * TILE_WORDS>), dim3(blocks / 2), dim3(512), 0, s, a);
+                    return;
+                }
+            }
             hipLaunchKernelGGL((ntt_fwd_cols<P, LOGN1>), dim3(blocks), dim3(256), 0, s, a);
+        }
         else
-            hipLaunchKernelGGL((ntt_inv_cols<typename std::conditional<P::WIDE, Fast, P>::type, LOGN1>), dim3(blocks),
-                               dim3(256), 0, s, a);
+        {
+            // (the inverse column pass is bound by its instruction stream, 93 % VALU-busy: wide tiles change nothing there)
+            typedef typename std::conditional<P::WIDE, Fast, P>::type Q;
+            hipLaunchKernelGGL((ntt_inv_cols<Q, LOGN1>), dim3(blocks), dim3(256), 0, s, a);
+        }
     }
 
     template <class P>
