@@ -151,7 +151,7 @@ namespace
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
 
-    // x >= K ? x - K : x   (one 64-bit add, one compare, two selects)
+    // x >= K ? x - K : x for x < 2K
     __device__ __forceinline__ u64 guard(u64 x, u64 K, u64 negK)
     {
         const u64 t = add64(x, negK);
@@ -199,7 +199,9 @@ namespace
         }
     };
 
-    __device__ __forceinline__ Source source(const NttArgs &a, const Where &w, u64 extra)
+    // wide_input: the transform takes operands below 4q (Wide column pass), so values modulo a prime q_J <= 4q go in
+    // as they are -- the transform is linear modulo q and every consumer reduces its output, only the class counts
+    __device__ __forceinline__ Source source(const NttArgs &a, const Where &w, u64 extra, bool wide_input)
     {
         Source s;
         s.q = s.ratio1 = s.Q = s.Qratio1 = s.half = s.fix = 0;
@@ -218,7 +220,7 @@ namespace
         {
             s.p = a.src + w.src_offset + extra;
             const u64 qs = a.mods[w.src_mod].q;
-            s.mode = qs > m.q ? 1 : 0; // copy when q_J <= q_I (evaluator.cpp:2643)
+            s.mode = (qs > m.q && !(wide_input && qs <= (m.q << 2))) ? 1 : 0; // copy when q_J <= q_I (evaluator.cpp:2643)
             s.close = qs < (m.q << 1);
         }
         else
@@ -554,7 +556,7 @@ namespace
         constexpr int C = TW / N1;             // columns per workgroup (TW / 16 threads)
         constexpr int SUB = 16 >> K1;          // consecutive rows per thread in round 1
         u64 *p = a.data + w.offset + w.tile * C;
-        const Source in = source(a, w, w.tile * C);
+        const Source in = source(a, w, w.tile * C, P::WIDE);
 
         const u32 c = threadIdx.x % C, tau = threadIdx.x / C;
         u64 x[16];
@@ -1020,7 +1022,7 @@ namespace
         u64 *p = a.data + w.offset;
         if (FWD)
         {
-            const Source in = source(a, w, 0);
+            const Source in = source(a, w, 0, false);
             for (u32 i = threadIdx.x; i < n; i += blockDim.x)
                 s[i] = in(i);
         }
