@@ -218,6 +218,9 @@ def main():
     ap.add_argument("--config5-pairs", type=int, default=8192)
     ap.add_argument("--config5-slice", type=int, default=64)
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
+    # rehearsal of the N > 1 code path on a one-GPU box: every rank on cuda:0, collectives over gloo (RCCL refuses two
+    # ranks on one device); the numbers of such a run mean nothing and the line says so
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus")
@@ -244,9 +247,18 @@ def main():
     from cat_amd import sharding
     from cat_amd.api import to_host
 
+    if args.rehearse_on_one_gpu:
+        import faulthandler
+
+        local_rank = 0
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        faulthandler.dump_traceback_later(120, exit=True)  # a rehearsal that hangs says where
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     gen = torch.Generator(device=device)
@@ -311,6 +323,8 @@ def main():
     bytes_per_op = 56 * L * N + 8 * N * (L + 2 * L * (L + 1) + 4 * L) + 2 * (2 * L - 1) * N * 8
 
     result = {
+        **({"rehearsal": "all ranks on one GPU over gloo: code-path check only, not a measurement"}
+           if args.rehearse_on_one_gpu else {}),
         "metric": METRIC,
         "value": ops_per_s,
         "unit": "ops/s",

@@ -49,9 +49,22 @@ def broadcast_key(key: torch.Tensor, src: int = 0, bucket_bytes: int = 256 << 20
         return key
     flat = key.view(-1)
     step = max(1, bucket_bytes // flat.element_size())
+    via_host = _host_staged(flat)
     for off in range(0, flat.numel(), step):
-        dist.broadcast(flat[off : off + step], src=src)
+        piece = flat[off : off + step]
+        if via_host:
+            staged = piece.cpu()
+            dist.broadcast(staged, src=src)
+            piece.copy_(staged)
+        else:
+            dist.broadcast(piece, src=src)
     return key
+
+
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo moves device tensors through host memory anyway; doing the copies here keeps its stream handling out of
+    the picture (rehearsals of the multi-rank path on one GPU, tests)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
 
 
 def gather_results(local: torch.Tensor, n_items: int, dst: Optional[int] = None) -> Optional[torch.Tensor]:
@@ -100,6 +113,8 @@ def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float
     world, _ = world_info()
     if world == 1:
         return value
+    if dist.get_backend() == "gloo":
+        device = None
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
