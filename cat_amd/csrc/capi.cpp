@@ -268,6 +268,15 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
             nm[i].inv_n_w = MulOp{ t.inv_n_w, hm.shoup(t.inv_n_w) };
             nm[i].inv_n3 = split3(hm, t.inv_n);
             nm[i].inv_n_w3 = split3(hm, t.inv_n_w);
+            int bits = 0;
+            while (bits < 64 && (hm.q >> bits))
+                ++bits;
+            nm[i].red_r = 0, nm[i].red_shift = 0, nm[i].pad = 0;
+            if (bits >= 36 && bits <= 60)
+            {
+                nm[i].red_r = (u32)((((unsigned __int128)1) << (31 + bits)) / hm.q);
+                nm[i].red_shift = (u32)(bits - 33);
+            }
         }
         const uint32_t k = ctx->k;
         ctx->h_inv_mod.assign((size_t)k * k, MulOp{ 0, 0 });

@@ -154,6 +154,7 @@ namespace
         const u32 I = grp / tiles, tile = grp - I * tiles;
         const u32 ki = I == g.d ? g.k - 1 : I;
         const u64 q = g.nmods[ki].q;
+        const u32 red_r = g.nmods[ki].red_r, red_shift = g.nmods[ki].red_shift;
         rm_stage_twiddles(lds, g.tw3 + ((size_t)ki * 3 << g.log_n), g.log_n, tile);
         __syncthreads();
         const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -222,7 +223,7 @@ namespace
             u64 ka[8], kb[8];
             rm_load8(ka, kp0);
             rm_load8(kb, kp1);
-            rm_rows<2, true>(x, tw, xs, t, q);
+            rm_rows<2, true>(x, tw, xs, t, q, red_r, red_shift);
 #pragma unroll
             for (int cidx = 0; cidx < 2; ++cidx)
             {
@@ -255,7 +256,7 @@ namespace
 #pragma unroll
             for (int a = 0; a < 8; ++a)
                 x[0][a] = ebase[(size_t)J0 * N + a * 32];
-            rm_rows<1, true>(x, tw, xs, t, q);
+            rm_rows<1, true>(x, tw, xs, t, q, red_r, red_shift);
             mac(x[0], J0, x[0], J0, false);
         }
         // d < 256: the reference's lazy counter never triggers an intermediate reduction (:2619-2707)

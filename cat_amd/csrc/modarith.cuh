@@ -240,7 +240,22 @@ struct __attribute__((aligned(16))) NttMod
     MulOp inv_n_w;  // inv_root_powers[n-1] * n^-1 mod q      (util/ntt.h:50-56)
     MulOp3 inv_n3;
     MulOp3 inv_n_w3;
+    // reduce_below_2q(): red_r = floor(2^(31+b) / q), red_shift = b - 33 for a prime of b >= 36 bits, else red_r = 0
+    u32 red_r, red_shift;
+    u64 pad;
 };
+
+// x < 16q < 2^64, q a prime of b >= 36 bits: x - e q in [0, 2q) with e = floor(x / q) or one less, estimated from the
+// high word: mulhi32(x_hi, floor(2^(31+b)/q)) = (x/q) 2^(b-33) - (less than 3), so e = that >> (b - 33) never exceeds
+// floor(x/q) and misses it by at most one.  5 instructions (v_mul_hi_u32, shift, v_mad_u64_u32, v_mul_lo_u32, add)
+// where the two conditional subtractions of 8q and 4q take 8 and leave the value below 4q only.
+__device__ __forceinline__ u64 reduce_below_2q(u64 x, u32 red_r, u32 red_shift, u64 nq)
+{
+    const u32 e = __umulhi((u32)(x >> 32), red_r) >> red_shift;
+    u64 r = x + (u64)e * (u32)nq;
+    r += (u64)(e * (u32)(nq >> 32)) << 32;
+    return r;
+}
 
 // Limb position -> modulus index map, passed to kernels by value (CAT_MAX_MODULI entries).
 struct LimbMap

@@ -735,6 +735,8 @@ namespace
             return;
         const u32 mod = a.map.id[grp];
         const u64 q = a.mods[mod].q, nq = 0 - q;
+        const u32 red_r = a.mods[mod].red_r, red_shift = a.mods[mod].red_shift;
+        const bool below_2q = WIDE && red_r != 0; // what rm_rows hands back
         rm_stage_twiddles(lds, reinterpret_cast<const u64 *>(a.tw) + ((size_t)mod * 3 << a.log_n), a.log_n, tile);
         __syncthreads();
         const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -768,7 +770,7 @@ namespace
                                      base + (u64)(2 * nx + 1 < a.n_polys ? 2 * nx + 1 : 2 * nx) * a.poly_stride + t};
                 rows8_load<2>(xn, src);
             }
-            rm_rows<2, WIDE>(x, tw, xs, t, q);
+            rm_rows<2, WIDE>(x, tw, xs, t, q, red_r, red_shift);
             const bool two = 2 * pi + 1 < a.n_polys;
             // third exchange: from 8 consecutive coefficients per thread to 16-byte pieces that are consecutive
             // across the lanes of a row, so that every store instruction writes whole 512-byte runs
@@ -783,7 +785,7 @@ namespace
                 {
                     u64 v = x[n][u];
                     if (!lazy)
-                        v = guard(guard(v, q << 1, nq << 1), q, nq);
+                        v = guard(below_2q ? v : guard(v, q << 1, nq << 1), q, nq);
                     // element e at e ^ ((e >> 4) & 7): the 16 lanes a ds_write_b64 serves together (t = 16k .. 16k+15)
                     // then hit 16 different 8-byte bank pairs (with (e >> 5) & 7, lanes t and t + 2 collided), and
                     // the 16-byte reads below stay conflict-free

@@ -98,8 +98,11 @@ namespace
 
     // last 8 stages of ND limb-rows held as x[n][a] = row[a * 32 + t]; result x[n][u] = row[8 t + u], values < 4q
     // WIDE: inputs < 16q, a subtraction of 8q before the even stages only (primes below 2^60)
+    // WIDE with red_r != 0 (NttMod, primes of 36 bits and more): the final reduction from 16q goes by an estimated
+    // quotient and the results are below 2q
     template <int ND, bool WIDE = false>
-    __device__ __forceinline__ void rm_rows(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q)
+    __device__ __forceinline__ void rm_rows(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q, u32 red_r = 0,
+                                            u32 red_shift = 0)
     {
         const u64 K = q << 2, negK = 0 - K, nq = 0 - q;
         rm_stage<ND, 1, WIDE ? 2 : 1>(x, tw, 1, K, negK, nq);
@@ -136,6 +139,15 @@ namespace
         }
         rm_stage<ND, 2, WIDE ? 2 : 1>(x, tw, 64 + 2 * t, K, negK, nq);
         rm_stage<ND, 4, WIDE ? 0 : 1>(x, tw, 128 + 2 * t, K, negK, nq, 192 + 2 * t);
+        if (WIDE && red_r != 0)
+        {
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    x[n][u] = reduce_below_2q(x[n][u], red_r, red_shift, nq);
+            return;
+        }
 #pragma unroll
         for (int n = 0; n < ND; ++n)
 #pragma unroll
