@@ -235,12 +235,11 @@ namespace
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                {
-                    mid[u] = 0;
-                    rm_mac(acc[cidx][u], mid[u], x[0][u], ka[u]);
-                    rm_mac(acc[cidx][u], mid[u], x[1][u], kb[u]);
-                    rm_fold(acc[cidx][u], mid[u]);
-                }
+                    rm_mac2(acc[cidx][u], mid[u], x[0][u], ka[u], x[1][u], kb[u]);
+#pragma unroll
+                for (int u = 0; u < 8; u += 4)
+                    rm_fold4(acc[cidx][u], acc[cidx][u + 1], acc[cidx][u + 2], acc[cidx][u + 3], mid[u], mid[u + 1],
+                             mid[u + 2], mid[u + 3]);
                 if (cidx == 0)
                 {
 #pragma unroll

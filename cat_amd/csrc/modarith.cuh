@@ -231,6 +231,56 @@ __device__ __forceinline__ void rm_fold(Acc &acc, u64 mid)
     acc.hi += mid >> 32;
 }
 
+// The same accumulation for TWO digits of one coefficient as one statement: the carry of the low product is consumed
+// three instructions after it is produced (gfx950 wants two wait states there) and the middle sum starts from the
+// literal 0, so no zeroing move.
+__device__ __forceinline__ void rm_mac2(Acc &acc, u64 &mid, u64 a0, u64 b0, u64 a1, u64 b1)
+{
+    u64 sc;
+    asm("v_mad_u64_u32 %0, %4, %5, %9, %0\n\t"
+        "v_mad_u64_u32 %3, vcc, %5, %11, 0\n\t"
+        "v_mad_u64_u32 %1, vcc, %7, %11, %1\n\t"
+        "v_mad_u64_u32 %3, vcc, %7, %9, %3\n\t"
+        "v_addc_co_u32 %2, vcc, 0, %2, %4\n\t"
+        "v_mad_u64_u32 %0, %4, %6, %10, %0\n\t"
+        "v_mad_u64_u32 %3, vcc, %6, %12, %3\n\t"
+        "v_mad_u64_u32 %1, vcc, %8, %12, %1\n\t"
+        "v_mad_u64_u32 %3, vcc, %8, %10, %3\n\t"
+        "v_addc_co_u32 %2, vcc, 0, %2, %4"
+        : "+v"(acc.lo), "+v"(acc.hi), "+v"(acc.cc), "=&v"(mid), "=&s"(sc)
+        : "v"((u32)a0), "v"((u32)a1), "v"((u32)(a0 >> 32)), "v"((u32)(a1 >> 32)), "v"((u32)b0), "v"((u32)b1),
+          "v"((u32)(b0 >> 32)), "v"((u32)(b1 >> 32))
+        : "vcc");
+}
+// rm_fold for four accumulators: the low word of mid goes into the high word of lo (carry counted in cc), its high word
+// into hi by one v_mad_u64_u32 (x 1); the compiler's form builds mid << 32 and mid >> 32 as register pairs with moves.
+__device__ __forceinline__ void rm_fold4(Acc &e0, Acc &e1, Acc &e2, Acc &e3, u64 m0, u64 m1, u64 m2, u64 m3)
+{
+    u32 h0 = (u32)(e0.lo >> 32), h1 = (u32)(e1.lo >> 32), h2 = (u32)(e2.lo >> 32), h3 = (u32)(e3.lo >> 32);
+    u64 s0, s1, s2, s3;
+    asm("v_add_co_u32 %0, %12, %0, %16\n\t"
+        "v_add_co_u32 %1, %13, %1, %17\n\t"
+        "v_add_co_u32 %2, %14, %2, %18\n\t"
+        "v_add_co_u32 %3, %15, %3, %19\n\t"
+        "v_mad_u64_u32 %4, vcc, %20, 1, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %21, 1, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %22, 1, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %23, 1, %7\n\t"
+        "v_addc_co_u32 %8, vcc, 0, %8, %12\n\t"
+        "v_addc_co_u32 %9, vcc, 0, %9, %13\n\t"
+        "v_addc_co_u32 %10, vcc, 0, %10, %14\n\t"
+        "v_addc_co_u32 %11, vcc, 0, %11, %15"
+        : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(e0.hi), "+v"(e1.hi), "+v"(e2.hi), "+v"(e3.hi), "+v"(e0.cc),
+          "+v"(e1.cc), "+v"(e2.cc), "+v"(e3.cc), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3)
+        : "v"((u32)m0), "v"((u32)m1), "v"((u32)m2), "v"((u32)m3), "v"((u32)(m0 >> 32)), "v"((u32)(m1 >> 32)),
+          "v"((u32)(m2 >> 32)), "v"((u32)(m3 >> 32))
+        : "vcc");
+    e0.lo = ((u64)h0 << 32) | (u32)e0.lo;
+    e1.lo = ((u64)h1 << 32) | (u32)e1.lo;
+    e2.lo = ((u64)h2 << 32) | (u32)e2.lo;
+    e3.lo = ((u64)h3 << 32) | (u32)e3.lo;
+}
+
 // Per-modulus constants of the NTT kernels (both arithmetic flavours)
 struct __attribute__((aligned(16))) NttMod
 {
