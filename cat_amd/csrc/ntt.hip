@@ -781,26 +781,28 @@ namespace
                     break;
                 rm_wave_sync();
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < 8; u += 2)
                 {
-                    u64 v = x[n][u];
+                    ulonglong2 v;
+                    v.x = x[n][u], v.y = x[n][u + 1];
                     if (!lazy)
-                        v = guard(below_2q ? v : guard(v, q << 1, nq << 1), q, nq);
-                    // element e at e ^ ((e >> 4) & 7): the 16 lanes a ds_write_b64 serves together (t = 16k .. 16k+15)
-                    // then hit 16 different 8-byte bank pairs (with (e >> 5) & 7, lanes t and t + 2 collided), and
-                    // the 16-byte reads below stay conflict-free
-                    xs[(8 * t + u) ^ ((t >> 1) & 7)] = v;
+                    {
+                        v.x = guard(below_2q ? v.x : guard(v.x, q << 1, nq << 1), q, nq);
+                        v.y = guard(below_2q ? v.y : guard(v.y, q << 1, nq << 1), q, nq);
+                    }
+                    // 16-byte pieces, piece index XOR (t >> 1) & 3: eight consecutive lanes of a ds_write_b128 (64-byte
+                    // stride: slots 0 and 4 of 8 only) land in eight different 16-byte slots, the pieces stay whole (no
+                    // swap of their halves on the way out) and the 16-byte reads below are consecutive across lanes up
+                    // to a constant XOR
+                    *reinterpret_cast<ulonglong2 *>(xs + ((8 * t + u) ^ (((t >> 1) & 3) << 1))) = v;
                 }
                 rm_wave_sync();
                 u64 *o = base + (u64)(2 * pi + n) * a.poly_stride;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                 {
-                    const u32 e = (i * 32 + t) * 2, sw = (4 * i + (t >> 3)) & 7;
-                    const ulonglong2 r = *reinterpret_cast<const ulonglong2 *>(xs + ((e ^ sw) & ~1u));
-                    ulonglong2 w;
-                    w.x = (sw & 1) ? r.y : r.x;
-                    w.y = (sw & 1) ? r.x : r.y;
+                    const u32 e = (i * 32 + t) * 2, sw = ((t >> 3) & 3) << 1; // writer lane 8 i + (t >> 2)
+                    const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(xs + (e ^ sw));
                     NT_STORE2(w, o + e);
                 }
             }
@@ -858,16 +860,19 @@ namespace
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                 {
-                    const u32 e = (i * 32 + t) * 2, sw = (2 * i + (t >> 4)) & 7;
-                    ulonglong2 w;
-                    w.x = (sw & 1) ? rn[n][i].y : rn[n][i].x;
-                    w.y = (sw & 1) ? rn[n][i].x : rn[n][i].y;
-                    *reinterpret_cast<ulonglong2 *>(xs + ((e ^ sw) & ~1u)) = w;
+                    // the mirror image of the forward kernel's last exchange: whole 16-byte pieces, piece index XOR
+                    // (lane >> 2) & 3 of the lane that reads them, 8 i + (t >> 2): a ds_read_b128 serves 16 lanes
+                    // at a time (a ds_write_b128 eight, hence (lane >> 1) & 3 in the forward kernel)
+                    const u32 e = (i * 32 + t) * 2, sw = ((2 * i + (t >> 4)) & 3) << 1;
+                    *reinterpret_cast<ulonglong2 *>(xs + (e ^ sw)) = rn[n][i];
                 }
                 rm_wave_sync();
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    x[n][u] = xs[(8 * t + u) ^ (t >> 2)];
+                for (int u = 0; u < 8; u += 2)
+                {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(xs + ((8 * t + u) ^ (((t >> 2) & 3) << 1)));
+                    x[n][u] = v.x, x[n][u + 1] = v.y;
+                }
             }
             if (pi + chunks < pairs)
                 fetch(rn, pi + chunks);

@@ -158,7 +158,7 @@ namespace
 
     // ---- inverse (Gentleman-Sande) counterpart: the FIRST 8 stages of SEAL's inverse network ------------------
     // (util/dwthandler.h:203-357) stay inside a row; stage T (gap 2^T) uses inv_tw[N - (N >> T) + 1 + row (128 >> T) + G],
-    // G < 128 >> T.  LDS entry of (T, G): 256 - (256 >> T) + G.  `table` = u64[3][N] of the limb in the shifted
+    // G < 128 >> T.  LDS entry of (T, G): 256 - (256 >> T) + G (T = 0: see rm_stage_twiddles_inv).  `table` = u64[3][N] of the limb in the shifted
     // inverse layout of the context (logical index i is stored at i - 1).
     __device__ __forceinline__ void rm_stage_twiddles_inv(u64 *lds, const u64 *table, u32 log_n, u32 tile)
     {
@@ -167,28 +167,35 @@ namespace
         if (e < 255)
         {
             const u32 T = 7 - (31 - __clz(255 - e)), G = e - (256 - (256 >> T));
+            // first stage (every lane reads its own four twiddles): pairs (G & 2) = 0 and = 2 in two halves of 64 words,
+            // so that both 16-byte reads are consecutive across lanes (as rm_entry does for the forward last stage)
+            const u32 pos = T == 0 ? ((G >> 2) << 1) + (G & 1) + ((G >> 1) & 1) * 64 : e;
 #pragma unroll
             for (int r = 0; r < RM_ROWS; ++r)
             {
                 const u32 idx = n - (n >> T) + 1 + (tile * RM_ROWS + r) * (128 >> T) + G;
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
-                    lds[(a * RM_ROWS + r) * 256 + e] = table[((size_t)a << log_n) + idx - 1];
+                    lds[(a * RM_ROWS + r) * 256 + pos] = table[((size_t)a << log_n) + idx - 1];
             }
         }
     }
 
     template <int ND, int CNT>
-    __device__ __forceinline__ void rm_stage_inv(u64 (&x)[ND][8], const u64 *tw, u32 entry, u64 K, u64 negK, u64 nq)
+    __device__ __forceinline__ void rm_stage_inv(u64 (&x)[ND][8], const u64 *tw, u32 entry, u64 K, u64 negK, u64 nq,
+                                                 u32 entry2 = 0xffffffffu)
     {
         constexpr int gap = 4 / CNT;
         MulOp3 w[CNT];
+        if (entry2 == 0xffffffffu)
+            entry2 = entry + 2;
 #pragma unroll
         for (int g = 0; g < CNT; ++g)
         {
-            const u64 qq = tw[2 * RM_ROWS * 256 + entry + g];
-            w[g].w0 = tw[entry + g];
-            w[g].w1 = tw[RM_ROWS * 256 + entry + g];
+            const u32 at = g < 2 ? entry + g : entry2 + (g - 2);
+            const u64 qq = tw[2 * RM_ROWS * 256 + at];
+            w[g].w0 = tw[at];
+            w[g].w1 = tw[RM_ROWS * 256 + at];
             w[g].q0 = (u32)qq;
             w[g].q1 = (u32)(qq >> 32);
         }
@@ -212,7 +219,7 @@ namespace
     {
         const u64 K = q << 2, negK = 0 - K, nq = 0 - q;
         const u32 A = t >> 2, c = t & 3, bh = t & 3;
-        rm_stage_inv<ND, 4>(x, tw, 0 + 4 * t, K, negK, nq);
+        rm_stage_inv<ND, 4>(x, tw, 2 * t, K, negK, nq, 64 + 2 * t);
         rm_stage_inv<ND, 2>(x, tw, 128 + 2 * t, K, negK, nq);
 #pragma unroll
         for (int n = 0; n < ND; ++n)
