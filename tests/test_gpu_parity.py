@@ -403,6 +403,40 @@ def test_switch_key_extreme_operands(cat, oracle, bits, count):
     ctx.close()
 
 
+@pytest.mark.parametrize("bits", [30, 35, 36, 37, 44, 58, 60])
+def test_wide_row_pass_final_reduction_by_prime_size(cat, oracle, bits):
+    """The wide-range row passes end with an estimated-quotient reduction from 16q for primes of 36 bits and more
+    (modarith.cuh reduce_below_2q) and with conditional subtractions below that: both sides of the boundary, the
+    smallest and the largest size, in the streaming forward transform (all-(q-1), zero and random inputs, inputs up
+    to 4q - 1) and in the fused key-switch kernel (every key word and target coefficient q - 1)."""
+    log_n, n, polys = 12, 4096, 6
+    primes = list(reversed(oracle.get_primes(2 * n, bits, 4)))
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_CKKS)
+    qs = np.array(primes, dtype=np.uint64)
+    ids = list(range(len(primes)))
+    rng = np.random.default_rng(3600 + bits)
+    x = rand_limbs(rng, primes, (polys,), n)
+    x[0] = (qs - 1)[:, None]
+    x[1] = 0
+    x[2, :, ::2] = (qs - 1)[:, None]
+    assert (host(ctx.ntt_forward(dev(x), lazy=False)) == octx.ntt_forward(x, ids, lazy=False)).all()
+    x4 = rand_limbs(rng, primes, (polys,), n, mult=4)
+    x4[0] = (4 * qs - 1)[:, None]
+    assert (host(ctx.ntt_forward(dev(x4), lazy=False)) == octx.ntt_forward(x4, ids, lazy=False)).all()
+    k = len(primes)
+    L = k - 1
+    key = np.broadcast_to((qs - 1)[None, None, :, None], (k - 1, 2, k, n)).copy()
+    enc = np.stack([octx.uniform(L, 2, 950 + b) for b in range(2)])
+    tgt = np.empty((2, L, n), dtype=np.uint64)
+    tgt[0] = (qs[:L] - 1)[:, None]
+    tgt[1] = octx.uniform(L, 1, 960)[0]
+    got = host(ctx.switch_key(dev(enc), dev(tgt), dev(key)))
+    exp = np.stack([octx.switch_key_inplace(enc[b], tgt[b], key) for b in range(2)])
+    assert (got == exp).all()
+    ctx.close()
+
+
 def test_scheme_contexts_reject_61_bit_primes(cat, oracle):
     """context.cu:202-206 (invalid_coeff_modulus_bit_count): user primes are at most 60 bits; a context without a scheme
     (transforms only) takes the 61-bit primes of Modulus."""
