@@ -287,6 +287,7 @@ namespace
     struct Exact
     {
         static constexpr bool WIDE = false;
+        static constexpr bool INV_WIDE = false;
         typedef MulOp Tw;
         typedef const MulOp *Table;
         struct Mod
@@ -340,6 +341,7 @@ namespace
     struct Fast
     {
         static constexpr bool WIDE = false;
+        static constexpr bool INV_WIDE = false;
         typedef MulOp3 Tw;
         struct Table
         {
@@ -349,6 +351,7 @@ namespace
         {
             u64 q, K, negK, nq;
             MulOp3 inv_n, inv_n_w;
+            u32 red_r, red_shift; // reduce_below_2q (InvWide)
         };
         __device__ static __forceinline__ Mod mod(const NttMod &m)
         {
@@ -359,6 +362,8 @@ namespace
             r.nq = 0 - m.q;
             r.inv_n = m.inv_n3;
             r.inv_n_w = m.inv_n_w3;
+            r.red_r = m.red_r;
+            r.red_shift = m.red_shift;
             return r;
         }
         // the inverse table is stored shifted by one entry (entry j = inv_root_powers[j + 1]) so that every
@@ -430,6 +435,23 @@ namespace
     {
         static constexpr bool WIDE = true;
     };
+    // Fast arithmetic with wide lazy ranges for INVERSE transforms whose primes all have 36 to 60 bits.  A Gentleman-
+    // Sande butterfly doubles the range of its sum and its product comes out below 4q whatever went in, so with values
+    // below 4q an even stage needs no reduction (sums below 8q, differences taken against 4q) and the odd stage after
+    // it (sums below 16q <= 2^64, differences against 8q) brings its sums below 2q with the estimated-quotient
+    // reduction (modarith.cuh reduce_below_2q, 5 instructions): 2.5 instructions per butterfly and stage instead of
+    // the 4 of a conditional subtraction in every stage.  The merged last stage multiplies both outputs and needs no
+    // reduction at all; it takes its difference against 8q when it sits at an odd stage.
+    struct InvWide : Fast
+    {
+        static constexpr bool INV_WIDE = true;
+    };
+    // reduction mode of inverse global stage G: 0 conditional subtraction of K (Exact: 2q, Fast: 4q), 1 none, 2 estimated
+    template <class P>
+    __device__ __forceinline__ constexpr int inv_mode(int G)
+    {
+        return !P::INV_WIDE ? 0 : (G & 1) ? 2 : 1;
+    }
     // guard mode of a forward stage: 0 none, 1 subtract K = 2q (Exact) / 4q (Fast), 2 subtract 8q
     template <class P>
     __device__ __forceinline__ constexpr int col_guard(int global_stage)
@@ -499,10 +521,11 @@ namespace
     }
 
     // Inverse (Gentleman-Sande) local stage S: register gap 1 << S, 8 >> S twiddles tw[root0 + g].
-    template <class P, int S>
+    template <class P, int S, int G = 0>
     __device__ __forceinline__ void inv_stage16(u64 (&x)[16], const typename P::Table &tw, u32 root0,
                                                 const typename P::Mod &m)
     {
+        constexpr int MODE = inv_mode<P>(G);
         constexpr int gap = 1 << S;
         constexpr int CNT = 8 >> S, CH = CNT < TW_CHUNK ? CNT : TW_CHUNK;
 #pragma unroll
@@ -518,15 +541,20 @@ namespace
                 {
                     const int i0 = g * 2 * gap + j;
                     const u64 u = x[i0], v = x[i0 + gap];
-                    x[i0] = guard(add64(u, v), m.K, m.negK);
-                    x[i0 + gap] = P::mul(add64(u, m.K) - v, w[g - g0], m);
+                    if constexpr (MODE == 0)
+                        x[i0] = guard(add64(u, v), m.K, m.negK);
+                    else if constexpr (MODE == 1)
+                        x[i0] = add64(u, v);
+                    else
+                        x[i0] = reduce_below_2q(add64(u, v), m.red_r, m.red_shift, m.nq);
+                    x[i0 + gap] = P::mul(add64(u, MODE == 2 ? m.K << 1 : m.K) - v, w[g - g0], m);
                 }
             }
         }
     }
 
     // Final inverse stage (single twiddle, merged n^-1): dwthandler.h:274-315.
-    template <class P, int S>
+    template <class P, int S, int G = 0>
     __device__ __forceinline__ void inv_last_stage16(u64 (&x)[16], const typename P::Mod &m)
     {
         constexpr int gap = 1 << S;
@@ -538,9 +566,20 @@ namespace
             for (int j = 0; j < gap; ++j)
             {
                 const int i0 = g * 2 * gap + j;
-                const u64 u = guard(x[i0], m.K, m.negK), v = x[i0 + gap];
-                x[i0] = P::mul(guard(add64(u, v), m.K, m.negK), wn, m);
-                x[i0 + gap] = P::mul(add64(u, m.K) - v, wnw, m);
+                if constexpr (std::is_base_of<Fast, P>::value)
+                {
+                    // operands below K = 4q and the split product takes any 64-bit word: no reduction before either
+                    // multiply (u + v and u + K - v stay below 8q < 2^64)
+                    const u64 u = x[i0], v = x[i0 + gap];
+                    x[i0] = P::mul(add64(u, v), wn, m);
+                    x[i0 + gap] = P::mul(add64(u, inv_mode<P>(G) == 2 ? m.K << 1 : m.K) - v, wnw, m);
+                }
+                else
+                {
+                    const u64 u = guard(x[i0], m.K, m.negK), v = x[i0 + gap];
+                    x[i0] = P::mul(guard(add64(u, v), m.K, m.negK), wn, m);
+                    x[i0 + gap] = P::mul(add64(u, m.K) - v, wnw, m);
+                }
             }
         }
     }
@@ -810,6 +849,7 @@ namespace
     }
 
     // ---- inverse, pass 1, poly-streaming form: the mirror image of ntt_fwd_rows8 ----------------------------
+    template <bool INV_WIDE>
     __global__ __launch_bounds__(256, 2) void ntt_inv_rows8(NttArgs a, u32 chunks)
     {
         __shared__ __align__(16) u64 lds[RM_TW_WORDS + RM_X_WORDS];
@@ -876,7 +916,7 @@ namespace
             }
             if (pi + chunks < pairs)
                 fetch(rn, pi + chunks);
-            rm_rows_inv<2>(x, tw, xs, t, q);
+            rm_rows_inv<2, INV_WIDE>(x, tw, xs, t, q, a.mods[mod].red_r, a.mods[mod].red_shift);
             const bool two = 2 * pi + 1 < a.n_polys;
 #pragma unroll
             for (int n = 0; n < 2; ++n)
@@ -918,10 +958,10 @@ namespace
             x[l] = s[t * 17 + l];
         // global stages 0..3: root index n - (n >> T) + 1 + group
         const u32 blk = row * 16 + t;
-        inv_stage16<P, 0>(x, tw, n - (n >> 0) + 1 + blk * 8, m);
-        inv_stage16<P, 1>(x, tw, n - (n >> 1) + 1 + blk * 4, m);
-        inv_stage16<P, 2>(x, tw, n - (n >> 2) + 1 + blk * 2, m);
-        inv_stage16<P, 3>(x, tw, n - (n >> 3) + 1 + blk * 1, m);
+        inv_stage16<P, 0, 0>(x, tw, n - (n >> 0) + 1 + blk * 8, m);
+        inv_stage16<P, 1, 1>(x, tw, n - (n >> 1) + 1 + blk * 4, m);
+        inv_stage16<P, 2, 2>(x, tw, n - (n >> 2) + 1 + blk * 2, m);
+        inv_stage16<P, 3, 3>(x, tw, n - (n >> 3) + 1 + blk * 1, m);
         wave_lds_sync();
 #pragma unroll
         for (int l = 0; l < 16; ++l)
@@ -931,10 +971,10 @@ namespace
         for (int h = 0; h < 16; ++h)
             x[h] = s[h * 17 + t];
         // global stages 4..7
-        inv_stage16<P, 0>(x, tw, n - (n >> 4) + 1 + row * 8, m);
-        inv_stage16<P, 1>(x, tw, n - (n >> 5) + 1 + row * 4, m);
-        inv_stage16<P, 2>(x, tw, n - (n >> 6) + 1 + row * 2, m);
-        inv_stage16<P, 3>(x, tw, n - (n >> 7) + 1 + row * 1, m);
+        inv_stage16<P, 0, 4>(x, tw, n - (n >> 4) + 1 + row * 8, m);
+        inv_stage16<P, 1, 5>(x, tw, n - (n >> 5) + 1 + row * 4, m);
+        inv_stage16<P, 2, 6>(x, tw, n - (n >> 6) + 1 + row * 2, m);
+        inv_stage16<P, 3, 7>(x, tw, n - (n >> 7) + 1 + row * 1, m);
 #pragma unroll
         for (int h = 0; h < 16; ++h)
             p[h * 16 + t] = x[h];
@@ -967,13 +1007,13 @@ namespace
         if (std::is_base_of<Fast, P>::value)
             __syncthreads(); // staged twiddles visible
         // global stages 8..11
-        inv_stage16<P, 0>(x, tw, n - (n >> 8) + 1 + tau * 8, m);
-        inv_stage16<P, 1>(x, tw, n - (n >> 9) + 1 + tau * 4, m);
-        inv_stage16<P, 2>(x, tw, n - (n >> 10) + 1 + tau * 2, m);
+        inv_stage16<P, 0, 8>(x, tw, n - (n >> 8) + 1 + tau * 8, m);
+        inv_stage16<P, 1, 9>(x, tw, n - (n >> 9) + 1 + tau * 4, m);
+        inv_stage16<P, 2, 10>(x, tw, n - (n >> 10) + 1 + tau * 2, m);
         if (K1 == 0)
-            inv_last_stage16<P, 3>(x, m);
+            inv_last_stage16<P, 3, 11>(x, m);
         else
-            inv_stage16<P, 3>(x, tw, n - (n >> 11) + 1 + tau, m);
+            inv_stage16<P, 3, 11>(x, tw, n - (n >> 11) + 1 + tau, m);
         if (K1 > 0)
         {
 #pragma unroll
@@ -987,13 +1027,13 @@ namespace
                 x[e] = lds[row * C + c];
             }
             // global stages 12 .. 12+K1-1 act on register stages S = 4-K1 .. 3; the last one is final
-            if (K1 == 4) inv_stage16<P, 0>(x, tw, n - (n >> 12) + 1, m);
-            if (K1 == 3) inv_stage16<P, 1>(x, tw, n - (n >> 12) + 1, m);
-            if (K1 == 4) inv_stage16<P, 1>(x, tw, n - (n >> 13) + 1, m);
-            if (K1 == 2) inv_stage16<P, 2>(x, tw, n - (n >> 12) + 1, m);
-            if (K1 == 3) inv_stage16<P, 2>(x, tw, n - (n >> 13) + 1, m);
-            if (K1 == 4) inv_stage16<P, 2>(x, tw, n - (n >> 14) + 1, m);
-            inv_last_stage16<P, 3>(x, m);
+            if (K1 == 4) inv_stage16<P, 0, 12>(x, tw, n - (n >> 12) + 1, m);
+            if (K1 == 3) inv_stage16<P, 1, 12>(x, tw, n - (n >> 12) + 1, m);
+            if (K1 == 4) inv_stage16<P, 1, 13>(x, tw, n - (n >> 13) + 1, m);
+            if (K1 == 2) inv_stage16<P, 2, 12>(x, tw, n - (n >> 12) + 1, m);
+            if (K1 == 3) inv_stage16<P, 2, 13>(x, tw, n - (n >> 13) + 1, m);
+            if (K1 == 4) inv_stage16<P, 2, 14>(x, tw, n - (n >> 14) + 1, m);
+            inv_last_stage16<P, 3, 11 + K1>(x, m);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e)
@@ -1112,8 +1152,17 @@ namespace
         }
         else
         {
-            // (the inverse column pass is bound by its instruction stream, 93 % VALU-busy: wide tiles change nothing there)
+            // (with the Fast policy the inverse column pass is bound by its instruction stream, 93 % VALU-busy, and wide
+            // tiles change nothing; InvWide's 93 instead of 103 instructions per coefficient leave it on its accesses)
             typedef typename std::conditional<P::WIDE, Fast, P>::type Q;
+            if constexpr (LOGN1 == 8 && P::INV_WIDE)
+            {
+                if (wide_tiles(a))
+                {
+                    hipLaunchKernelGGL((ntt_inv_cols<Q, LOGN1, 2 * TILE_WORDS>), dim3(blocks / 2), dim3(512), 0, s, a);
+                    return;
+                }
+            }
             hipLaunchKernelGGL((ntt_inv_cols<Q, LOGN1>), dim3(blocks), dim3(256), 0, s, a);
         }
     }
@@ -1182,7 +1231,7 @@ namespace
                     chunks = max_chunks;
                 if (chunks < 1)
                     chunks = 1;
-                hipLaunchKernelGGL(ntt_inv_rows8, dim3((u32)(groups * chunks)), dim3(256), 0, s, a, chunks);
+                hipLaunchKernelGGL(ntt_inv_rows8<P::INV_WIDE>, dim3((u32)(groups * chunks)), dim3(256), 0, s, a, chunks);
             }
             else
                 hipLaunchKernelGGL((ntt_inv_rows<typename std::conditional<P::WIDE, Fast, P>::type>),
@@ -1201,6 +1250,19 @@ namespace cat
         for (uint32_t i = 0; i < n_groups; ++i)
             if (ctx->hmods[map.id[i]].q >> 60)
                 return false;
+        return true;
+    }
+
+    // every prime of 36 to 60 bits: the inverse transform's wide ranges (policy InvWide) need 16q <= 2^64 and the
+    // estimated-quotient reduction
+    static bool ntt_inv_wide(const cat_ctx *ctx, const LimbMap &map, uint32_t n_groups)
+    {
+        for (uint32_t i = 0; i < n_groups; ++i)
+        {
+            const u64 q = ctx->hmods[map.id[i]].q;
+            if ((q >> 60) || !(q >> 35))
+                return false;
+        }
         return true;
     }
 
@@ -1289,6 +1351,8 @@ namespace cat
         a.tw = forward ? (const void *)ctx->d_tw3_fwd : (const void *)ctx->d_tw3_inv;
         if (forward && ctx->log_n >= 12 && ntt_wide(ctx, map, (n_limbs + limb_group - 1) / limb_group))
             return launch_policy<Wide>(ctx, forward, a, s, fuse && fuse->first_pass_only);
+        if (!forward && ctx->log_n >= 12 && ntt_inv_wide(ctx, map, (n_limbs + limb_group - 1) / limb_group))
+            return launch_policy<InvWide>(ctx, forward, a, s, false);
         return launch_policy<Fast>(ctx, forward, a, s, fuse && fuse->first_pass_only);
     }
 } // namespace cat

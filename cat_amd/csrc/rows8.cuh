@@ -181,9 +181,11 @@ namespace
         }
     }
 
-    template <int ND, int CNT>
+    // MODE: reduction of the sums: 0 conditional subtraction of K = 4q, 1 none (operands below 4q), 2 estimated quotient
+    // from below 16q to below 2q with the differences taken against 8q (ntt.hip, policy InvWide)
+    template <int ND, int CNT, int MODE = 0>
     __device__ __forceinline__ void rm_stage_inv(u64 (&x)[ND][8], const u64 *tw, u32 entry, u64 K, u64 negK, u64 nq,
-                                                 u32 entry2 = 0xffffffffu)
+                                                 u32 entry2 = 0xffffffffu, u32 red_r = 0, u32 red_shift = 0)
     {
         constexpr int gap = 4 / CNT;
         MulOp3 w[CNT];
@@ -208,19 +210,28 @@ namespace
                 {
                     const int i0 = g * 2 * gap + j;
                     const u64 u = x[n][i0], v = x[n][i0 + gap];
-                    x[n][i0] = rm_guard(add64(u, v), K, negK);
-                    x[n][i0 + gap] = mul_split(add64(u, K) - v, w[g], nq);
+                    if (MODE == 0)
+                        x[n][i0] = rm_guard(add64(u, v), K, negK);
+                    else if (MODE == 1)
+                        x[n][i0] = add64(u, v);
+                    else
+                        x[n][i0] = reduce_below_2q(add64(u, v), red_r, red_shift, nq);
+                    x[n][i0 + gap] = mul_split(add64(u, MODE == 2 ? K << 1 : K) - v, w[g], nq);
                 }
     }
 
     // in: x[n][u] = row[8 t + u] (values < 4q); out: x[n][a] = row[a * 32 + t], values < 4q
-    template <int ND>
-    __device__ __forceinline__ void rm_rows_inv(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q)
+    // W (policy InvWide): stages alternate between no reduction and the estimated-quotient one
+    template <int ND, bool W = false>
+    __device__ __forceinline__ void rm_rows_inv(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q, u32 red_r = 0,
+                                                u32 red_shift = 0)
     {
+        constexpr int MA = W ? 1 : 0, MB = W ? 2 : 0; // even / odd global stage
+        constexpr u32 E2 = 0xffffffffu;
         const u64 K = q << 2, negK = 0 - K, nq = 0 - q;
         const u32 A = t >> 2, c = t & 3, bh = t & 3;
-        rm_stage_inv<ND, 4>(x, tw, 2 * t, K, negK, nq, 64 + 2 * t);
-        rm_stage_inv<ND, 2>(x, tw, 128 + 2 * t, K, negK, nq);
+        rm_stage_inv<ND, 4, MA>(x, tw, 2 * t, K, negK, nq, 64 + 2 * t, red_r, red_shift);
+        rm_stage_inv<ND, 2, MB>(x, tw, 128 + 2 * t, K, negK, nq, E2, red_r, red_shift);
 #pragma unroll
         for (int n = 0; n < ND; ++n)
         {
@@ -233,9 +244,9 @@ namespace
             for (int b = 0; b < 8; ++b)
                 x[n][b] = xs[((((b & 1) << 2) | c) << 5) | (A << 2) | ((b >> 1) ^ c)]; // element A*32 + 4b + c
         }
-        rm_stage_inv<ND, 4>(x, tw, 192 + 4 * A, K, negK, nq);
-        rm_stage_inv<ND, 2>(x, tw, 224 + 2 * A, K, negK, nq);
-        rm_stage_inv<ND, 1>(x, tw, 240 + A, K, negK, nq);
+        rm_stage_inv<ND, 4, MA>(x, tw, 192 + 4 * A, K, negK, nq, E2, red_r, red_shift);
+        rm_stage_inv<ND, 2, MB>(x, tw, 224 + 2 * A, K, negK, nq, E2, red_r, red_shift);
+        rm_stage_inv<ND, 1, MA>(x, tw, 240 + A, K, negK, nq, E2, red_r, red_shift);
 #pragma unroll
         for (int n = 0; n < ND; ++n)
         {
@@ -248,8 +259,8 @@ namespace
             for (int a = 0; a < 8; ++a)
                 x[n][a] = xs[(a << 5) | (((t >> 2) ^ a) << 2) | c]; // element a*32 + t
         }
-        rm_stage_inv<ND, 4>(x, tw, 248, K, negK, nq);
-        rm_stage_inv<ND, 2>(x, tw, 252, K, negK, nq);
-        rm_stage_inv<ND, 1>(x, tw, 254, K, negK, nq);
+        rm_stage_inv<ND, 4, MB>(x, tw, 248, K, negK, nq, E2, red_r, red_shift);
+        rm_stage_inv<ND, 2, MA>(x, tw, 252, K, negK, nq, E2, red_r, red_shift);
+        rm_stage_inv<ND, 1, MB>(x, tw, 254, K, negK, nq, E2, red_r, red_shift);
     }
 } // namespace
