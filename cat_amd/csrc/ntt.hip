@@ -1126,8 +1126,9 @@ namespace
         }
     }
 
-    // plain forward transforms of large batches (N = 2^16): column tiles twice as wide, 14.7 against 15.1 ms on
-    // BASELINE config 2 (same box); 1024-thread tiles of 64 columns measured slower (16.0 ms)
+    // forward transforms of large batches (N = 2^16), plain or with the key-switch raise: column tiles twice as wide,
+    // 14.7 against 15.1 ms on BASELINE config 2 and -2.7 % on the raise pass of the metric op (same box); 1024-thread
+    // tiles of 64 columns measured slower (16.0 ms)
     inline bool wide_tiles(const NttArgs &a)
     {
         return (u64)a.n_limbs * a.n_polys >= 2048;
@@ -1142,7 +1143,7 @@ namespace
         {
             if constexpr (LOGN1 == 8 && std::is_base_of<Fast, P>::value)
             {
-                if (!a.src && wide_tiles(a))
+                if (wide_tiles(a))
                 {
                     hipLaunchKernelGGL((ntt_fwd_cols<P, LOGN1, false, 2 * TILE_WORDS>), dim3(blocks / 2), dim3(512), 0, s, a);
                     return;
