@@ -7,7 +7,7 @@ HDR := include/cat_amd.h cat_amd/csrc/context.hpp cat_amd/csrc/host_math.hpp cat
 OBJ := $(patsubst cat_amd/csrc/%,build/%.o,$(SRC))
 LIB := cat_amd/lib/libcat_amd.so
 
-all: $(LIB) oracle facade_test random_test
+all: $(LIB) oracle facade_test random_test modulus_test
 
 $(LIB): $(OBJ)
 	@mkdir -p cat_amd/lib
@@ -35,8 +35,12 @@ random_test: tests/cpp/random_test
 tests/cpp/random_test: tests/cpp/test_random.cpp cat_amd/host/seal_hip_random.hpp oracle
 	g++ -std=c++17 -O2 -Wall $< -o $@ -Loracle -lseal_oracle -ldl -Wl,-rpath,'$$ORIGIN/../../oracle'
 
+modulus_test: tests/cpp/modulus_test
+tests/cpp/modulus_test: tests/cpp/test_modulus.cpp cat_amd/host/seal_hip_modulus.hpp
+	g++ -std=c++17 -O2 -Wall $< -o $@
+
 clean:
 	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean facade_test random_test
+.PHONY: all oracle clean facade_test random_test modulus_test

@@ -101,7 +101,7 @@ namespace seal
         }
         std::size_t uint64_count() const noexcept
         {
-            return value_ ? 1 : 0;
+            return 1; // also for the zero modulus (modulus.h: uint64_count_ = 1; tests/seal/modulus.cpp:21)
         }
         const std::array<std::uint64_t, 3> &const_ratio() const noexcept
         {

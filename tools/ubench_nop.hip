@@ -21,14 +21,12 @@ __global__ __launch_bounds__(256) void k_guard_plain(u64 *out, u64 K, int iters)
         {
             u64 t;
             u32 lo = (u32)x[i], hi = (u32)(x[i] >> 32);
-            asm volatile("v_lshl_add_u64 %0, %3, 0, %4\n\t"
-                         "v_cmp_le_u64 vcc, %5, %3\n\t"
-                         "s_nop 1\n\t"
-                         "v_cndmask_b32 %1, %1, %0, vcc\n\t"
-                         "v_cndmask_b32 %2, %2, %0, vcc"
-                         : "=&v"(t), "+v"(lo), "+v"(hi)
-                         : "v"(x[i]), "v"(negK), "v"(K)
-                         : "vcc");
+            asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"(x[i]), "v"(negK));
+            // compare into VCC, the two wait states the compiler would insert, then the selects (volatile statements
+            // keep their order; VCC carries the mask from one to the next)
+            asm volatile("v_cmp_le_u64 vcc, %0, %1\n\ts_nop 1" : : "v"(K), "v"(x[i]) : "vcc");
+            asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(lo) : "v"((u32)t) : "vcc");
+            asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(hi) : "v"((u32)(t >> 32)) : "vcc");
             x[i] = (((u64)hi << 32) | lo) + it;
         }
     }
