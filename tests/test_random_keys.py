@@ -2,8 +2,9 @@
 generation, encrypt_zero_*; oracle/seal_oracle.c) and the facade's host-side counterpart
 (cat_amd/host/seal_hip_random.hpp).
 
-Pinning: BLAKE2b against RFC 7693's vector and Python's hashlib; BLAKE2Xb against the reference's own BLAKE2 C files
-compiled as they lie (oracle/_ref/libblake2_ref.so, built by oracle/Makefile when /root/reference is present).  The
+Pinning: BLAKE2b against RFC 7693's vector and Python's hashlib; BLAKE2Xb against golden vectors made with the
+reference's own BLAKE2 C files (tests/golden/blake2xb_vectors.json) and, where that build is present, against it
+directly (oracle/_ref/libblake2_ref.so, built by oracle/Makefile when /root/reference is present).  The
 reference holds no known answers for the sampler or key bytes (its tests are statistical, native/tests/seal/
 randomgen.cpp:65-225, and decrypt-and-compare), so those are pinned the same way: distribution checks and
 decrypt-and-compare -- "parity unpinned" at the byte level beyond the PRNG stream."""
@@ -33,6 +34,24 @@ def test_blake2b_rfc7693_and_hashlib(oracle):
         for outlen in (1, 20, 32, 64):
             for key in (b"", b"k", bytes(range(64))):
                 assert oracle.blake2b(data, outlen, key) == hashlib.blake2b(data, digest_size=outlen, key=key).digest()
+
+
+def test_blake2xb_golden_vectors(oracle):
+    """tests/golden/blake2xb_vectors.json: outputs of the reference's own BLAKE2 files on seeded inputs, kept as data
+    (made by tests/golden/make_blake2xb_vectors.py); needs no reference build."""
+    import json
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_blake2xb_vectors import cases
+
+    rows = json.load(open(os.path.join(ROOT, "tests", "golden", "blake2xb_vectors.json")))["vectors"]
+    got = list(cases())
+    assert len(got) == len(rows) == 109
+    for (outlen, data, key), row in zip(got, rows):
+        assert (outlen, len(data), len(key)) == (row["outlen"], row["inlen"], row["keylen"])
+        out = oracle.blake2xb(data, outlen, key)
+        assert out[:16].hex() == row["head"] and hashlib.sha256(out).hexdigest() == row["sha256"]
 
 
 def test_blake2xb_matches_the_reference_build(oracle):
