@@ -513,6 +513,8 @@ def main():
             "inverse_GBps": alg_bytes / (i_ms * 1e-3) / 1e9,
             "roundtrip_exact": roundtrip,
             "copy_GBps": copy_gbps,  # measured streaming copy (bytes read + written)
+            # the transform makes two passes over its data: two plain device copies of it against the transform's time
+            "two_copies_over_forward": (2 * alg_bytes / (copy_gbps * 1e9)) / (f_ms * 1e-3),
         }
         if not roundtrip:
             print(json.dumps({"error": "NTT round trip mismatch", **result}))
