@@ -65,9 +65,8 @@ namespace
             u32 j = 0;
             for (; j + 2 <= g.isz; j += 2)
             {
-                u64 mid = 0;
-                rm_mac(acc, mid, stage[j * 256 + threadIdx.x], row[j]);
-                rm_mac(acc, mid, stage[(j + 1) * 256 + threadIdx.x], row[j + 1]);
+                u64 mid;
+                rm_mac2(acc, mid, stage[j * 256 + threadIdx.x], row[j], stage[(j + 1) * 256 + threadIdx.x], row[j + 1]);
                 rm_fold(acc, mid);
             }
             if (j < g.isz)
