@@ -54,7 +54,46 @@ namespace
             stage[j * 256 + threadIdx.x] = mul_shoup(x, g.inv_punc[j].op, g.inv_punc[j].quo, q);
         }
         u64 *dst = g.out + p * g.out_stride + c;
-        for (u32 o = 0; o < g.osz; ++o)
+        u32 o = 0;
+        // four output residues at a time: one read of the staged residues serves four dot products, and their folds go
+        // through rm_fold4 (3 instructions per accumulator instead of the compiler's 8)
+        for (; o + 4 <= g.osz; o += 4)
+        {
+            const u64 *row = g.matrix + (u64)o * g.isz;
+            Acc acc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                acc[k].lo = acc[k].hi = 0, acc[k].cc = 0;
+            u32 j = 0;
+            for (; j + 2 <= g.isz; j += 2)
+            {
+                const u64 x0 = stage[j * 256 + threadIdx.x], x1 = stage[(j + 1) * 256 + threadIdx.x];
+                u64 mid[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    rm_mac2(acc[k], mid[k], x0, row[k * g.isz + j], x1, row[k * g.isz + j + 1]);
+                rm_fold4(acc[0], acc[1], acc[2], acc[3], mid[0], mid[1], mid[2], mid[3]);
+            }
+            if (j < g.isz)
+            {
+                const u64 x0 = stage[j * 256 + threadIdx.x];
+                u64 mid[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                {
+                    mid[k] = 0;
+                    rm_mac(acc[k], mid[k], x0, row[k * g.isz + j]);
+                }
+                rm_fold4(acc[0], acc[1], acc[2], acc[3], mid[0], mid[1], mid[2], mid[3]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const DevMod m = g.mods[g.omap.id[o + k]];
+                dst[(u64)(g.out_off + o + k) << g.log_n] = barrett128(acc[k].lo, acc[k].hi + acc[k].cc, m.q, m.ratio0, m.ratio1);
+            }
+        }
+        for (; o < g.osz; ++o)
         {
             const DevMod m = g.mods[g.omap.id[o]];
             const u64 *row = g.matrix + (u64)o * g.isz;
