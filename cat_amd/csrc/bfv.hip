@@ -237,7 +237,12 @@ namespace
         const u64 x0 = x[0], x1 = x[poly], y0 = y[0], y1 = y[poly];
         u64 *o = g.out + b * 3 * poly + off;
         o[0] = mul_mod(x0, y0, m.q, m.ratio0, m.ratio1);
-        o[poly] = add_mod(mul_mod(x1, y0, m.q, m.ratio0, m.ratio1), mul_mod(x0, y1, m.q, m.ratio0, m.ratio1), m.q);
+        // the middle term as one 128-bit sum and ONE reduction (operands below 2^63: the sum is below 2^127, and
+        // Barrett-128 takes any 128-bit value); the canonical result is that of the reference's two products and add
+        u64 lo = 0, hi = 0;
+        mac128(lo, hi, x1, y0);
+        mac128(lo, hi, x0, y1);
+        o[poly] = barrett128(lo, hi, m.q, m.ratio0, m.ratio1);
         o[2 * poly] = mul_mod(x1, y1, m.q, m.ratio0, m.ratio1);
     }
 
