@@ -1,5 +1,6 @@
 # Builds libcat_amd.so (hand-written HIP for gfx950 + the C ABI) and the CPU oracle.
 HIPCC ?= /opt/rocm/bin/hipcc
+# gfx950 (MI355X) is the only supported target: the kernels' tiles assume its 160 KB of LDS per CU (ntt.hip refuses others)
 ARCH ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude
 SRC := cat_amd/csrc/capi.cpp cat_amd/csrc/comm.cpp cat_amd/csrc/ntt.hip cat_amd/csrc/polyops.hip cat_amd/csrc/keyswitch.hip cat_amd/csrc/bfv.hip

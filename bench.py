@@ -201,7 +201,7 @@ def cpu_description():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (default: WORLD_SIZE under a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="ciphertext pairs per step per GPU")
@@ -222,10 +222,12 @@ def main():
     # ranks on one device); the numbers of such a run mean nothing and the line says so
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:  # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's word counts
+        args.gpus = int(env_world) if env_world else 1
     if args.gpus < 1:
         ap.error("--gpus")
 
-    env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(env_world or "1")
@@ -252,7 +254,8 @@ def main():
 
         local_rank = 0
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        faulthandler.dump_traceback_later(120, exit=True)  # a rehearsal that hangs says where
+        # a rehearsal that hangs says where; the limit is the one tests/test_zy_bench_two_ranks.py gives the whole run
+        faulthandler.dump_traceback_later(280, exit=True)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_on_one_gpu:
@@ -282,8 +285,20 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    # The only collective, outside the timed region: the product's own cat_key_broadcast (C ABI) on an RCCL communicator
+    # made here (one rank per GPU over xGMI).  The gloo rehearsal on one GPU keeps torch.distributed's broadcast: RCCL
+    # refuses two ranks on one device.
+    comm = None
+    if world > 1 and not args.rehearse_on_one_gpu:
+        comm = sharding.RcclComm(world, rank)
+        dist.barrier()
     t0 = time.perf_counter()
-    sharding.broadcast_key(key, src=0)  # RCCL over xGMI: the only collective, outside the timed region
+    if comm is not None:
+        ctx.key_broadcast(key, comm.handle, root=0)
+        key_bcast_via = "cat_key_broadcast (RCCL communicator of the bench's own)"
+    else:
+        sharding.broadcast_key(key, src=0)
+        key_bcast_via = "torch.distributed broadcast (gloo rehearsal)" if world > 1 else "single process: no collective"
     torch.cuda.synchronize()
     key_bcast_s = time.perf_counter() - t0 if world > 1 else 0.0
     prod = torch.empty((B, 3, L, N), dtype=torch.int64, device=device)
@@ -348,6 +363,7 @@ def main():
             "algorithmic_bytes_per_op": bytes_per_op,
             "op_hbm_floor_frac": (ops_per_s / world) * bytes_per_op / (HBM_PEAK_GBS * 1e9),
             "key_broadcast_s": key_bcast_s,
+            "key_broadcast_via": key_bcast_via,
         },
     }
 
@@ -443,10 +459,15 @@ def main():
         del x, y, prod, out, key
         ctx.close()
         torch.cuda.empty_cache()
-        result["config5"] = config5_leg(args, torch, dist, cat_amd, sharding, to_host, world, rank, local_rank, device, gen)
-        if result["config5"].get("parity_checked") is False:
+        result["config5"] = config5_leg(args, torch, dist, cat_amd, sharding, to_host, world, rank, local_rank, device, gen,
+                                        comm)
+        # rank 0 holds the verdict: every rank learns it and exits non-zero with it
+        bad = 1.0 if result["config5"].get("parity_checked") is False else 0.0
+        if sharding.max_over_ranks(bad, device) > 0:
             if rank == 0:
                 print(json.dumps({"error": "config 5: GPU result differs from the CPU oracle", **result}))
+            if world > 1:
+                dist.destroy_process_group()
             sys.exit(1)
         x = y = prod = out = None
 
@@ -524,10 +545,12 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.barrier()  # rank 0 may still be in its roofline leg
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 
-def config5_leg(args, torch, dist, cat_amd, sharding, to_host, world, rank, local_rank, device, gen):
+def config5_leg(args, torch, dist, cat_amd, sharding, to_host, world, rank, local_rank, device, gen, comm=None):
     """8192 (ct_a, ct_b) pairs, CKKS N=32768, BFVDefault(32768) = 15 ciphertext primes + special; rank r owns the
     contiguous slice shard_range(8192, world, r), resident in HBM, and runs multiply + relinearize over it in slices
     of `--config5-slice` pairs; one shared relinearization key, broadcast once.  Strong scaling: the job is fixed."""
@@ -551,7 +574,10 @@ def config5_leg(args, torch, dist, cat_amd, sharding, to_host, world, rank, loca
     if world > 1:
         dist.barrier()
     t0 = _t.perf_counter()
-    sharding.broadcast_key(key, src=0)
+    if comm is not None:
+        ctx.key_broadcast(key, comm.handle, root=0)  # the C ABI's collective, as in the metric leg
+    else:
+        sharding.broadcast_key(key, src=0)
     torch.cuda.synchronize()
     bcast_s = _t.perf_counter() - t0 if world > 1 else 0.0
 

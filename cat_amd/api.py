@@ -104,6 +104,18 @@ class Context:
     def reserve(self, nbytes: int):
         _check(self.lib.cat_ctx_reserve(self.h, nbytes))
 
+    def workspace_need(self, batch: int) -> int:
+        return int(self.lib.cat_ctx_workspace_need(self.h, batch))
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.cat_ctx_workspace_bytes(self.h))
+
+    def workspace_grew(self) -> int:
+        return int(self.lib.cat_ctx_workspace_grew(self.h))
+
+    def set_workspace_strict(self, on: bool):
+        _check(self.lib.cat_ctx_set_workspace_strict(self.h, 1 if on else 0))
+
     # -- a1/a2 -----------------------------------------------------------------------------------------
     def ntt_forward(self, x: torch.Tensor, limb_ids=None, lazy=False):
         """x: [..., n_limbs, N], in place."""

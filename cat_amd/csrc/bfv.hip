@@ -436,11 +436,12 @@ namespace
         return reinterpret_cast<const MulOp *>(lv.d_blob + off);
     }
 
-    cat_status level_of(cat_ctx *ctx, uint32_t L, const BfvLevel **out)
+    // dev: the caller's DeviceScope (the context's device stays current until the entry point returns)
+    cat_status level_of(cat_ctx *ctx, uint32_t L, const BfvLevel **out, DeviceScope &dev)
     {
-        if (!ctx)
-            return fail(CAT_ERR_INVALID_ARG, "ctx");
-        CAT_HIP(hipSetDevice(ctx->device));
+        const cat_status ds = dev.enter(ctx);
+        if (ds != CAT_OK)
+            return ds;
         if (ctx->scheme != CAT_SCHEME_BFV)
             return fail(CAT_ERR_LOGIC, "unsupported scheme");
         if (L == 0 || L >= ctx->bfv.size() || !ctx->bfv[L].ready)
@@ -596,7 +597,8 @@ cat_status cat_fastbconv_m_tilde(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d
                                  cat_stream s)
 {
     const BfvLevel *lv;
-    cat_status st = level_of(ctx, L, &lv);
+    DeviceScope dev;
+    cat_status st = level_of(ctx, L, &lv, dev);
     if (st != CAT_OK)
         return st;
     if (n_polys && (!d_in || !d_out))
@@ -610,7 +612,8 @@ cat_status cat_fastbconv_m_tilde(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d
 cat_status cat_sm_mrq(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys, cat_stream s)
 {
     const BfvLevel *lv;
-    cat_status st = level_of(ctx, L, &lv);
+    DeviceScope dev;
+    cat_status st = level_of(ctx, L, &lv, dev);
     if (st != CAT_OK)
         return st;
     if (n_polys && (!d_in || !d_out))
@@ -625,7 +628,8 @@ cat_status cat_fast_floor(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, u
                           cat_stream s)
 {
     const BfvLevel *lv;
-    cat_status st = level_of(ctx, L, &lv);
+    DeviceScope dev;
+    cat_status st = level_of(ctx, L, &lv, dev);
     if (st != CAT_OK)
         return st;
     if (n_polys && (!d_in || !d_out))
@@ -641,16 +645,17 @@ cat_status cat_fastbconv_sk(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out,
                             cat_stream s)
 {
     const BfvLevel *lv;
-    cat_status st = level_of(ctx, L, &lv);
+    DeviceScope dev;
+    cat_status st = level_of(ctx, L, &lv, dev);
     if (st != CAT_OK)
         return st;
     if (n_polys && (!d_in || !d_out))
         return fail(CAT_ERR_INVALID_ARG, "input");
     if (((uintptr_t)d_in | (uintptr_t)d_out) & 15)
         return fail(CAT_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
-    u64 *conv = (u64 *)workspace(ctx, (size_t)n_polys * (L + 1) * ctx->n * sizeof(u64));
+    u64 *conv = (u64 *)workspace(ctx, ws_words_fastbconv_sk(ctx->n, L, n_polys) * sizeof(u64));
     if (!conv)
-        return CAT_ERR_NOMEM;
+        return workspace_status(ctx);
     return run_fastbconv_sk(ctx, *lv, (const u64 *)d_in, (u64)lv->Bsk * ctx->n, conv, (u64 *)d_out, (u64)L * ctx->n,
                             n_polys, (hipStream_t)s);
 }
@@ -659,7 +664,8 @@ cat_status cat_bfv_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d
                             uint32_t batch, cat_stream stream)
 {
     const BfvLevel *lvp;
-    cat_status st = level_of(ctx, L, &lvp);
+    DeviceScope dev;
+    cat_status st = level_of(ctx, L, &lvp, dev);
     if (st != CAT_OK)
         return st;
     if (batch == 0)
@@ -678,9 +684,11 @@ cat_status cat_bfv_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d
     //                    tq [b][3][L][N] | tB [b][3][Bsk][N] | fl [b][3][Bsk][N]
     const size_t w_inq = b * 4 * pq, w_inB = b * 4 * pB, w_lift = b * 4 * (Bsk + 1) * N, w_tq = b * 3 * pq,
                  w_tB = b * 3 * pB, w_fl = b * 3 * pB;
-    u64 *ws = (u64 *)workspace(ctx, (w_inq + w_inB + w_lift + w_tq + w_tB + w_fl) * sizeof(u64));
+    if (w_inq + w_inB + w_lift + w_tq + w_tB + w_fl != ws_words_bfv_multiply(N, L, Bsk, b))
+        return fail(CAT_ERR_LOGIC, "workspace formula out of step");
+    u64 *ws = (u64 *)workspace(ctx, ws_words_bfv_multiply(N, L, Bsk, b) * sizeof(u64));
     if (!ws)
-        return CAT_ERR_NOMEM;
+        return workspace_status(ctx);
     u64 *inq = ws, *inB = inq + w_inq, *lift = inB + w_inB, *tq = lift + w_lift, *tB = tq + w_tq, *fl = tB + w_tB;
     // steps (1)-(3), evaluator.cpp:452-490: per input polynomial, lazy NTT in q; lift to Bsk, lazy NTT in Bsk
     CAT_HIP(hipMemcpy2DAsync(inq, 4 * pq * sizeof(u64), d_x, 2 * pq * sizeof(u64), 2 * pq * sizeof(u64), batch,

@@ -2,6 +2,7 @@
 // construction (table precompute + upload) and dispatch to the HIP kernels.
 #include "context.hpp"
 
+#include <atomic>
 #include <cstring>
 #include <initializer_list>
 #include <mutex>
@@ -23,20 +24,22 @@ static __device__ __align__(256) unsigned char cat_noalloc_scratch[CAT_NOALLOC_S
 namespace
 {
     constexpr int MAX_DEVICES = 64;
-    std::mutex g_scratch_mutex;
-    void *g_scratch_ptr[MAX_DEVICES] = {};
+    std::mutex g_scratch_mutex; // serialises the one-time look-up per device; readers do not take it
+    std::atomic<void *> g_scratch_ptr[MAX_DEVICES] = {};
 
     // once per device, with that device current (called from cat_ctx_create after hipSetDevice)
     cat_status noalloc_scratch_init(int device)
     {
         if (device < 0 || device >= MAX_DEVICES)
             return CAT_OK; // such a device simply has no no-allocation entry point (it reports that itself)
+        if (g_scratch_ptr[device].load(std::memory_order_acquire))
+            return CAT_OK;
         std::lock_guard<std::mutex> lock(g_scratch_mutex);
-        if (g_scratch_ptr[device])
+        if (g_scratch_ptr[device].load(std::memory_order_relaxed))
             return CAT_OK;
         void *p = nullptr;
         CAT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(cat_noalloc_scratch)));
-        g_scratch_ptr[device] = p;
+        g_scratch_ptr[device].store(p, std::memory_order_release);
         return CAT_OK;
     }
 
@@ -44,8 +47,8 @@ namespace
     {
         if (device < 0 || device >= MAX_DEVICES)
             return nullptr;
-        std::lock_guard<std::mutex> lock(g_scratch_mutex);
-        return g_scratch_ptr[device];
+        // written once per device before any context of that device exists (cat_ctx_create): a plain acquire load
+        return g_scratch_ptr[device].load(std::memory_order_acquire);
     }
 }
 
@@ -70,8 +73,19 @@ namespace cat
 
     void *workspace(cat_ctx *ctx, size_t bytes)
     {
+        ctx->ws_status = CAT_OK;
         if (bytes <= ctx->ws_bytes)
             return ctx->ws;
+        if (ctx->ws_strict)
+        {
+            // strict mode (cat_ctx_set_workspace_strict): growing means a device-wide synchronisation, hipFree and
+            // hipMalloc inside an asynchronous call; the caller asked to be told instead
+            set_error("the workspace would have to grow to " + std::to_string(bytes) + " bytes (cat_ctx_reserve it first)");
+            ctx->ws_status = CAT_ERR_LOGIC;
+            return nullptr;
+        }
+        ctx->ws_status = CAT_ERR_NOMEM;
+        ++ctx->ws_grew;
         // earlier launches may still use the old block
         if (hipDeviceSynchronize() != hipSuccess)
         {
@@ -95,7 +109,29 @@ namespace cat
         }
         ctx->ws = p;
         ctx->ws_bytes = want;
+        ctx->ws_status = CAT_OK;
         return p;
+    }
+
+    cat_status DeviceScope::enter_device(int device)
+    {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess)
+            return hip_fail(e, "hipGetDevice");
+        if (prev != device)
+        {
+            e = hipSetDevice(device);
+            if (e != hipSuccess)
+                return hip_fail(e, "hipSetDevice");
+            switched = true;
+        }
+        return CAT_OK;
+    }
+    cat_status DeviceScope::enter(const cat_ctx *ctx)
+    {
+        if (!ctx)
+            return fail(CAT_ERR_INVALID_ARG, "ctx");
+        return enter_device(ctx->device);
     }
 
     cat_status make_map(const cat_ctx *ctx, const uint32_t *limb_ids, uint32_t n_limbs, LimbMap &out)
@@ -119,16 +155,6 @@ namespace cat
 
 namespace
 {
-    cat_status check(cat_ctx *ctx)
-    {
-        if (!ctx)
-            return fail(CAT_ERR_INVALID_ARG, "ctx");
-        hipError_t e = hipSetDevice(ctx->device);
-        if (e != hipSuccess)
-            return hip_fail(e, "hipSetDevice");
-        return CAT_OK;
-    }
-
     // the kernels move 16 bytes per lane (ulonglong2): every device operand must be 16-byte aligned
     cat_status aligned16(std::initializer_list<const void *> ptrs)
     {
@@ -192,9 +218,11 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
     }
     if ((scheme == CAT_SCHEME_BFV || scheme == CAT_SCHEME_BGV) && (plain_modulus < 2 || (plain_modulus >> 60) != 0))
         return fail(CAT_ERR_INVALID_ARG, "plain_modulus is invalid");
-    CAT_HIP(hipSetDevice(device));
+    DeviceScope dev;
     {
-        const cat_status st = noalloc_scratch_init(device);
+        cat_status st = dev.enter_device(device);
+        if (st == CAT_OK)
+            st = noalloc_scratch_init(device);
         if (st != CAT_OK)
             return st;
     }
@@ -352,7 +380,8 @@ cat_status cat_ctx_destroy(cat_ctx *ctx)
 {
     if (!ctx)
         return CAT_OK;
-    (void)hipSetDevice(ctx->device);
+    DeviceScope dev;
+    (void)dev.enter(ctx);
     (void)hipDeviceSynchronize();
     destroy_bfv_levels(ctx);
     if (ctx->d_mods) (void)hipFree(ctx->d_mods);
@@ -371,35 +400,54 @@ cat_status cat_ctx_destroy(cat_ctx *ctx)
 
 cat_status cat_ctx_reserve(cat_ctx *ctx, size_t bytes)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
-    return workspace(ctx, bytes) || bytes == 0 ? CAT_OK : CAT_ERR_NOMEM;
+    // reserving is the sanctioned way to grow: strict mode does not apply to it
+    const bool strict = ctx->ws_strict;
+    ctx->ws_strict = false;
+    const uint64_t grew = ctx->ws_grew;
+    void *p = workspace(ctx, bytes);
+    ctx->ws_strict = strict;
+    ctx->ws_grew = grew;
+    return p || bytes == 0 ? CAT_OK : workspace_status(ctx);
+}
+
+cat_status cat_ctx_set_workspace_strict(cat_ctx *ctx, int on)
+{
+    if (!ctx)
+        return fail(CAT_ERR_INVALID_ARG, "ctx");
+    ctx->ws_strict = on != 0;
+    return CAT_OK;
+}
+
+uint64_t cat_ctx_workspace_grew(const cat_ctx *ctx)
+{
+    return ctx ? ctx->ws_grew : 0;
 }
 
 size_t cat_ctx_workspace_need(const cat_ctx *ctx, uint32_t batch)
 {
-    // the largest request any entry point makes for `batch` ciphertexts (size <= 3) at any level of this context;
-    // keep in step with launch_switch_key / galois_inplace / launch_rescale / cat_mod_drop / cat_bfv_multiply
+    // the largest request any entry point makes for `batch` ciphertexts (size <= 3) at any level of this context: the
+    // maximum of the launchers' own formulas (context.hpp ws_words_*); every one of them grows with the level
     if (!ctx || batch == 0)
         return 0;
     const size_t N = ctx->n, b = batch, k = ctx->k;
     const size_t L = k > 1 ? k - 1 : 1;
     size_t words = 0;
+    auto take = [&](size_t w) { words = w > words ? w : words; };
     if (k > 1 && ctx->scheme != CAT_SCHEME_NONE)
-    {
-        const size_t ks = b * (L + (L + 1) * L + 2 * (L + 1) + 2 * L + 4) * N;
-        words = ks + b * 2 * L * N; // apply_galois keeps the permuted copy behind the key-switch region
-    }
-    const size_t polys = b * 3;
-    const size_t rescale = polys * N + 2 * polys * (k - 1) * N; // level k
-    words = rescale > words ? rescale : words;
+        take(ws_words_galois(N, L, b)); // >= ws_words_switch_key with or without the rescale tail
+    take(ws_words_rescale(N, k, b * 3)); // a rescale / mod switch may start at the key level
+    take(ws_words_mod_drop(N, k, b * 3));
     if (ctx->scheme == CAT_SCHEME_BFV)
-    {
-        const size_t Bsk = L + 2; // |B| = L + 1 at the largest level, plus m_sk
-        const size_t bfv = b * (4 * L + 4 * Bsk + 4 * (Bsk + 1) + 3 * L + 3 * Bsk + 3 * Bsk) * N;
-        words = bfv > words ? bfv : words;
-    }
+        for (size_t l = 1; l < ctx->bfv.size(); ++l)
+            if (ctx->bfv[l].ready)
+            {
+                take(ws_words_bfv_multiply(N, l, ctx->bfv[l].Bsk, b));
+                take(ws_words_fastbconv_sk(N, l, b * 3));
+            }
     return words * sizeof(u64);
 }
 
@@ -435,7 +483,8 @@ uint64_t cat_ctx_modulus(const cat_ctx *ctx, uint32_t i)
 
 cat_status cat_malloc(cat_ctx *ctx, size_t bytes, void **d_ptr)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if (!d_ptr)
@@ -446,7 +495,8 @@ cat_status cat_malloc(cat_ctx *ctx, size_t bytes, void **d_ptr)
 
 cat_status cat_free(cat_ctx *ctx, void *d_ptr)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     CAT_HIP(hipFree(d_ptr));
@@ -455,7 +505,8 @@ cat_status cat_free(cat_ctx *ctx, void *d_ptr)
 
 cat_status cat_upload(cat_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     CAT_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
@@ -464,7 +515,8 @@ cat_status cat_upload(cat_ctx *ctx, void *d_dst, const void *h_src, size_t bytes
 
 cat_status cat_download(cat_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     CAT_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
@@ -473,7 +525,8 @@ cat_status cat_download(cat_ctx *ctx, void *h_dst, const void *d_src, size_t byt
 
 cat_status cat_stream_sync(cat_ctx *ctx, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     CAT_HIP(hipStreamSynchronize((hipStream_t)s));
@@ -483,7 +536,8 @@ cat_status cat_stream_sync(cat_ctx *ctx, cat_stream s)
 static cat_status ntt_common(cat_ctx *ctx, bool fwd, uint64_t *d_data, const uint32_t *limb_ids, uint32_t n_limbs,
                              uint32_t n_polys, int lazy, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if (!d_data && n_limbs && n_polys)
@@ -513,7 +567,8 @@ cat_status cat_ntt_inverse(cat_ctx *ctx, uint64_t *d_data, const uint32_t *limb_
 static cat_status ew_common(cat_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, uint64_t *out,
                             const uint32_t *limb_ids, uint32_t n_limbs, uint32_t n_polys, cat_stream s, bool binary)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if (n_limbs && n_polys)
@@ -567,7 +622,8 @@ cat_status cat_modulo(cat_ctx *ctx, const uint64_t *a, uint64_t *out, const uint
 static cat_status scalar_common(cat_ctx *ctx, int op, const uint64_t *a, const uint64_t *scalars, uint64_t *out,
                                 const uint32_t *ids, uint32_t nl, uint32_t np, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if (nl && np && (!a || !out))
@@ -614,7 +670,8 @@ static cat_status level_check(cat_ctx *ctx, uint32_t L, bool needs_next)
 cat_status cat_ckks_multiply(cat_ctx *ctx, const uint64_t *x, const uint64_t *y, uint64_t *out, uint32_t L,
                              uint32_t batch, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if ((st = level_check(ctx, L, false)) != CAT_OK)
@@ -644,7 +701,8 @@ uint64_t cat_bgv_inv_q_last_mod_t(const cat_ctx *ctx, uint32_t L)
 
 cat_status cat_ckks_square(cat_ctx *ctx, const uint64_t *x, uint64_t *out, uint32_t L, uint32_t batch, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if ((st = level_check(ctx, L, false)) != CAT_OK)
@@ -661,7 +719,8 @@ cat_status cat_ckks_square(cat_ctx *ctx, const uint64_t *x, uint64_t *out, uint3
 static cat_status plain_common(cat_ctx *ctx, int op, const uint64_t *ct, const uint64_t *plain, size_t plain_stride,
                                uint64_t *out, uint32_t L, uint32_t size, uint32_t batch, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if ((st = level_check(ctx, L, false)) != CAT_OK)
@@ -701,7 +760,8 @@ cat_status cat_sub_plain(cat_ctx *ctx, const uint64_t *ct, const uint64_t *plain
 cat_status cat_switch_key(cat_ctx *ctx, uint64_t *enc, const uint64_t *target, const uint64_t *key, uint32_t L,
                           uint32_t batch, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if (ctx->scheme == CAT_SCHEME_NONE || ctx->k < 2)
@@ -728,7 +788,8 @@ cat_status cat_switch_key(cat_ctx *ctx, uint64_t *enc, const uint64_t *target, c
 
 cat_status cat_relinearize(cat_ctx *ctx, uint64_t *ct3, const uint64_t *key, uint32_t L, uint32_t batch, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if (!key)
@@ -752,7 +813,8 @@ cat_status cat_relinearize(cat_ctx *ctx, uint64_t *ct3, const uint64_t *key, uin
 cat_status cat_relinearize_rescale(cat_ctx *ctx, uint64_t *ct3, const uint64_t *key, uint64_t *out, uint32_t L,
                                    uint32_t batch, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if (!key)
@@ -787,7 +849,8 @@ cat_status cat_relinearize_rescale(cat_ctx *ctx, uint64_t *ct3, const uint64_t *
 cat_status cat_rescale(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t L, uint32_t size, uint32_t batch,
                        cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if ((st = level_check(ctx, L, true)) != CAT_OK)
@@ -805,7 +868,8 @@ cat_status cat_rescale_noalloc(cat_ctx *ctx, const uint64_t *in, uint64_t *out, 
 {
     // cat_rescale with its temporaries in the static device array above: no hipMalloc / hipFree / allocating
     // library routine on this path (argument checks, kernel launches and nothing else)
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if ((st = level_check(ctx, L, true)) != CAT_OK)
@@ -828,7 +892,8 @@ cat_status cat_rescale_noalloc(cat_ctx *ctx, const uint64_t *in, uint64_t *out, 
 cat_status cat_rescale_strided(cat_ctx *ctx, const uint64_t *in, size_t in_stride, uint64_t *out, size_t out_stride,
                                uint32_t L, uint32_t size, uint32_t batch, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if ((st = level_check(ctx, L, true)) != CAT_OK)
@@ -846,7 +911,8 @@ cat_status cat_rescale_strided(cat_ctx *ctx, const uint64_t *in, size_t in_strid
 cat_status cat_mod_drop(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t L, uint32_t size, uint32_t batch,
                         cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if ((st = level_check(ctx, L, true)) != CAT_OK)
@@ -858,10 +924,10 @@ cat_status cat_mod_drop(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_
         return st;
     if (in == out && polys > 1)
     {
-        const size_t bytes = (size_t)polys * (L - 1) * ctx->n * sizeof(u64);
+        const size_t bytes = ws_words_mod_drop(ctx->n, L, polys) * sizeof(u64);
         u64 *ws = (u64 *)workspace(ctx, bytes);
         if (!ws)
-            return CAT_ERR_NOMEM;
+            return workspace_status(ctx);
         st = launch_drop_limb(ctx, (const u64 *)in, ws, L, polys, (hipStream_t)s);
         if (st != CAT_OK)
             return st;
@@ -908,7 +974,8 @@ static cat_status galois_check(cat_ctx *ctx, const uint64_t *in, uint64_t *out, 
 cat_status cat_apply_galois_ntt(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t elt, uint32_t nl,
                                 uint32_t np, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if ((st = galois_check(ctx, in, out, elt)) != CAT_OK)
@@ -920,7 +987,8 @@ cat_status cat_apply_galois_ntt(cat_ctx *ctx, const uint64_t *in, uint64_t *out,
 cat_status cat_apply_galois(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uint32_t elt, const uint32_t *ids,
                             uint32_t nl, uint32_t np, cat_stream s)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if ((st = galois_check(ctx, in, out, elt)) != CAT_OK)
@@ -961,7 +1029,8 @@ cat_status cat_apply_galois_rescale(cat_ctx *ctx, uint64_t *ct, uint32_t elt, co
 static cat_status galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, const uint64_t *key, uint32_t L, uint32_t batch,
                                  cat_stream s, uint64_t *rescale_out)
 {
-    cat_status st = check(ctx);
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
     if (ctx->scheme == CAT_SCHEME_NONE || ctx->k < 2)
@@ -980,10 +1049,10 @@ static cat_status galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, const
     // target perm(c1) in place, one ciphertext stride apart (:2410-2449).  The permuted copy must survive
     // launch_switch_key's own workspace use, so it is carved from the same block, after the key-switch region.
     const size_t N = ctx->n, ctw = (size_t)2 * L * N;
-    const size_t ks_words = (size_t)batch * ((size_t)L + (size_t)(L + 1) * L + 2 * (L + 1) + 2 * L + 4) * N;
-    u64 *ws = (u64 *)workspace(ctx, (ks_words + (size_t)batch * ctw) * sizeof(u64));
+    const size_t ks_words = ws_words_switch_key(N, L, batch, true);
+    u64 *ws = (u64 *)workspace(ctx, ws_words_galois(N, L, batch) * sizeof(u64));
     if (!ws)
-        return CAT_ERR_NOMEM;
+        return workspace_status(ctx);
     u64 *perm = ws + ks_words;
     const u64 *tgt = perm + (size_t)L * N;
     const bool ntt = ctx->scheme == CAT_SCHEME_CKKS || ctx->scheme == CAT_SCHEME_BGV; // :2429

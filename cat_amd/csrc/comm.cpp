@@ -23,11 +23,26 @@ namespace
         if (g_tried)
             return g_bcast != nullptr;
         g_tried = true;
-        // a librccl the process has loaded already (e.g. the one bundled with PyTorch) is found by its soname first
+        // The communicator belongs to the RCCL instance that created it: use the ncclBroadcast already visible in the
+        // process (the caller's RCCL, e.g. the copy PyTorch bundles, or one the caller loaded with RTLD_GLOBAL) before
+        // loading any copy of our own -- a comm must never cross two RCCL instances.
+        g_bcast = (bcast_fn)dlsym(RTLD_DEFAULT, "ncclBroadcast");
+        if (g_bcast)
+        {
+            g_errstr = (errstr_fn)dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+            return true;
+        }
         void *h = nullptr;
         for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" })
-            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr)
+        {
+            // RTLD_NOLOAD first: a copy loaded without RTLD_GLOBAL is in the process but not in the default scope
+            if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) != nullptr)
                 break;
+        }
+        if (!h)
+            for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" })
+                if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr)
+                    break;
         if (!h)
             return false;
         g_bcast = (bcast_fn)dlsym(h, "ncclBroadcast");
@@ -39,9 +54,12 @@ namespace
 extern "C" cat_status cat_key_broadcast(cat_ctx *ctx, void *comm, uint64_t *d_key, size_t n_words, int root,
                                         size_t bucket_words, cat_stream s)
 {
-    if (!ctx)
-        return cat::fail(CAT_ERR_INVALID_ARG, "ctx");
-    CAT_HIP(hipSetDevice(ctx->device));
+    cat::DeviceScope dev;
+    {
+        const cat_status st = dev.enter(ctx);
+        if (st != CAT_OK)
+            return st;
+    }
     if (!comm || n_words == 0)
         return CAT_OK; // one process holds the key already
     if (!d_key)

@@ -68,6 +68,9 @@ struct cat_ctx
 
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    uint64_t ws_grew = 0;   // times the workspace had to grow inside a call (synchronise + hipFree + hipMalloc)
+    bool ws_strict = false; // cat_ctx_set_workspace_strict: a call that would grow it fails with CAT_ERR_LOGIC instead
+    cat_status ws_status = CAT_OK; // why the last workspace() request returned nullptr
 
     std::vector<cat::BfvLevel> bfv; // index L
 
@@ -85,8 +88,48 @@ namespace cat
     void set_error(const std::string &msg);
     cat_status fail(cat_status code, const std::string &msg);
     cat_status hip_fail(hipError_t e, const char *what);
-    // Grows the context workspace to at least `bytes`; returns nullptr (and sets the error) on failure.
+    // Grows the context workspace to at least `bytes`; returns nullptr (and sets the error and ctx->ws_status) on
+    // failure: out of memory, or a growth refused in strict mode.
     void *workspace(cat_ctx *ctx, size_t bytes);
+    inline cat_status workspace_status(const cat_ctx *ctx) { return ctx->ws_status == CAT_OK ? CAT_ERR_NOMEM : ctx->ws_status; }
+
+    // Workspace words of every entry point that takes temporaries.  The launchers size their request with these and
+    // cat_ctx_workspace_need takes their maximum, so the two cannot drift apart.
+    inline size_t ws_words_switch_key(size_t N, size_t L, size_t batch, bool with_rescale)
+    {
+        // t_target [b][L] | ext [b][L+1][L] | prod [b][2][L+1] | tmp [b][2][L] | last [b][2][2] (relinearize + rescale)
+        return batch * (L + (L + 1) * L + 2 * (L + 1) + 2 * L + (with_rescale ? 4 : 0)) * N;
+    }
+    inline size_t ws_words_galois(size_t N, size_t L, size_t batch)
+    {
+        return ws_words_switch_key(N, L, batch, true) + batch * 2 * L * N; // the permuted copy behind the key-switch region
+    }
+    inline size_t ws_words_rescale(size_t N, size_t L, size_t polys)
+    {
+        return polys * N + 2 * polys * (L - 1) * N; // last | tmp | stage (aliased output)
+    }
+    inline size_t ws_words_mod_drop(size_t N, size_t L, size_t polys) { return polys * (L - 1) * N; }
+    inline size_t ws_words_fastbconv_sk(size_t N, size_t L, size_t polys) { return polys * (L + 1) * N; }
+    inline size_t ws_words_bfv_multiply(size_t N, size_t L, size_t Bsk, size_t batch)
+    {
+        // inq [b][4][L] | inB [b][4][Bsk] | lift [b][4][Bsk+1] | tq [b][3][L] | tB [b][3][Bsk] | fl [b][3][Bsk]
+        return batch * (4 * L + 4 * Bsk + 4 * (Bsk + 1) + 3 * L + 3 * Bsk + 3 * Bsk) * N;
+    }
+
+    // Makes the context's device current for the duration of an entry point and restores the caller's device on the
+    // way out (the entry points used to leave the calling thread on the context's device).
+    struct DeviceScope
+    {
+        int prev = -1;
+        bool switched = false;
+        cat_status enter(const cat_ctx *ctx);
+        cat_status enter_device(int device);
+        ~DeviceScope()
+        {
+            if (switched)
+                (void)hipSetDevice(prev);
+        }
+    };
     cat_status make_map(const cat_ctx *ctx, const uint32_t *limb_ids, uint32_t n_limbs, LimbMap &out);
 
     // ---- kernel launchers (ntt.hip, polyops.hip, keyswitch.hip, bfv.hip) ----

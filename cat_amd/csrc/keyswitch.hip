@@ -676,9 +676,12 @@ namespace cat
         const size_t w_prod = (size_t)batch * 2 * rns * N;
         const size_t w_tmp = (size_t)batch * 2 * d * N;
         const size_t w_last = rescale_out ? (size_t)batch * 2 * 2 * N : 0;
-        u64 *ws = (u64 *)workspace(ctx, (w_target + w_ext + w_prod + w_tmp + w_last) * sizeof(u64));
+        static_assert(sizeof(u64) == 8, "");
+        if (w_target + w_ext + w_prod + w_tmp + w_last != ws_words_switch_key(N, d, batch, rescale_out != nullptr))
+            return fail(CAT_ERR_LOGIC, "workspace formula out of step");
+        u64 *ws = (u64 *)workspace(ctx, ws_words_switch_key(N, d, batch, rescale_out != nullptr) * sizeof(u64));
         if (!ws)
-            return CAT_ERR_NOMEM;
+            return workspace_status(ctx);
         u64 *t_target = ws, *ext = t_target + w_target, *prod = ext + w_ext, *tmp = prod + w_prod, *last = tmp + w_tmp;
         if (rescale_out && (!ckks || log_n < 12 || d < 2))
             return fail(CAT_ERR_LOGIC, "unsupported fused transform");
@@ -953,9 +956,9 @@ namespace cat
                 return fail(CAT_ERR_INVALID_ARG, "operands exceed the static scratch buffer");
         }
         else
-            ws = (u64 *)workspace(ctx, (w_last + 2 * w_tmp) * sizeof(u64));
+            ws = (u64 *)workspace(ctx, ws_words_rescale(N, L, polys) * sizeof(u64)); // = w_last + 2 * w_tmp
         if (!ws)
-            return CAT_ERR_NOMEM;
+            return workspace_status(ctx);
         u64 *last = ws, *tmp = last + w_last, *stage = tmp + w_tmp; // stage is used only when alias (never with scratch)
         RescaleArgs g;
         g.in = in;

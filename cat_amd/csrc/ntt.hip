@@ -30,23 +30,24 @@
 #include <cstdlib>
 #include <type_traits>
 
+// The tilings below are sized for gfx950: 160 KB of LDS per CU (the 8192-word column tiles take 70 KB per workgroup, the
+// streaming row passes 64 KB at two workgroups per CU) and 64-lane waves.  Other targets are not supported.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "cat_amd's kernels are written for gfx950 (MI355X): build with --offload-arch=gfx950"
+#endif
+
 namespace
 {
     constexpr int ROW_LEN = 256;      // N2
     constexpr int ROW_PITCH = 272;    // 256 + 256/16 padding words (bank-conflict-free transposes)
     constexpr int TILE_WORDS = 4096;
 #ifndef ROWS8_TARGET_BLOCKS
-#define ROWS8_TARGET_BLOCKS 8192 // poly-streaming row passes: workgroups aimed at (4096 and 16384 measured 1 % slower)
+#define ROWS8_TARGET_BLOCKS 8192 // poly-streaming row passes: workgroups aimed at (4096 and 16384 measured 1 % slower, 1024 and 2048 6 and 3 %)
 #endif
 
     // streaming accesses of the poly-streaming row passes (data touched once per launch): non-temporal hints
-#ifdef CAT_NO_NT
-#define NT_LOAD(p) (*(p))
-#define NT_STORE(v, p) (*(p) = (v))
-#else
 #define NT_LOAD(p) __builtin_nontemporal_load(p)
 #define NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#endif
     typedef u64 u64x2 __attribute__((ext_vector_type(2)));
     __device__ __forceinline__ ulonglong2 NT_LOAD2(const u64 *p)
     {
@@ -113,13 +114,19 @@ namespace
         u32 poly, limb;
     };
 
-    // limb is the slowest index so that concurrently running workgroups share one prime's twiddles in L2
+    // Row passes (POLY_MAJOR = false): limb is the slowest index so that concurrently running workgroups share one
+    // prime's row twiddles in L2 (1.5 MB per prime at N = 2^16).  Column passes (POLY_MAJOR = true) need 6 KB of
+    // twiddles per prime, staged in LDS, and walk the buffer front to back instead -- tile, limb, polynomial: the
+    // workgroups in flight then cover one contiguous window rather than the same offsets of many objects a power of two
+    // apart, which HBM serves 8-10 % faster (profiles/r03_pass_shapes.txt: 5.13 -> 5.55 TB/s for this tile shape;
+    // config 2 forward 14.26 -> 13.93 ms, metric op +0.9 %, same box)
+    template <bool POLY_MAJOR = false>
     __device__ __forceinline__ Where locate(const NttArgs &a, u32 b, u32 tiles)
     {
         Where w;
         w.tile = b % tiles;
         const u32 rest = b / tiles;
-        const u32 poly = rest % a.n_polys, limb = rest / a.n_polys;
+        const u32 poly = POLY_MAJOR ? rest / a.n_limbs : rest % a.n_polys, limb = POLY_MAJOR ? rest % a.n_limbs : rest / a.n_polys;
         const u32 grp = limb / a.limb_group;
         w.mod = a.map.id[grp];
         w.skip = a.skip_diag && (limb - grp * a.limb_group == grp);
@@ -140,15 +147,6 @@ namespace
         __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-
-    // Workgroup barrier that orders LDS accesses only: global loads already requested stay in flight across it
-    // (__syncthreads() also waits for every outstanding global access of the wave).
-    __device__ __forceinline__ void lds_barrier()
-    {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
 
     // x >= K ? x - K : x for x < 2K
@@ -648,8 +646,10 @@ namespace
     template <class P, int LOGN1, bool DUAL = false, int TW = TILE_WORDS>
     __global__ __launch_bounds__(TW / 16, 4) void ntt_fwd_cols(NttArgs a)
     {
+        static_assert(TW / 16 >= 256, "stage_col_twiddles copies with the first 256 threads of the workgroup");
+        static_assert((TW + 3 * 256) * sizeof(u64) <= 80 * 1024, "two column workgroups per CU must fit 160 KB of LDS");
         __shared__ u64 lds[TW];
-        const Where w = locate(a, blockIdx.x, ROW_LEN / (TW >> LOGN1));
+        const Where w = locate<true>(a, blockIdx.x, ROW_LEN / (TW >> LOGN1));
         if (w.skip)
             return;
         const typename P::Mod m = P::mod(a.mods[w.mod]);
@@ -752,17 +752,10 @@ namespace
     // streams the rows of `n_polys / chunks` polynomials through them, two polynomials in flight per thread and
     // the next pair already requested.  Against ntt_fwd_rows: no per-tile twiddle traffic from L2 (3x the data
     // volume there) and nothing but the data stream in the vector-memory queue.
-    template <int ND>
-    __device__ __forceinline__ void rows8_load(u64 (&x)[2][8], const u64 *const (&src)[2])
-    {
-#pragma unroll
-        for (int n = 0; n < ND; ++n)
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-                x[n][a] = NT_LOAD(src[n] + a * 32);
-    }
-
-    template <bool WIDE>
+    // ND: polynomials in flight per thread (they share every twiddle read from LDS).  ND = 1 halves the bytes a thread
+    // has in flight, which the access-only skeleton likes (profiles/r03_pass_shapes.txt: 5.41 against 4.96 TB/s), but the
+    // kernel itself takes 3.5 % longer with it (config 2 forward 14.60 against 14.08 ms, same box): ND = 2 stays
+    template <bool WIDE, int ND = 2>
     __global__ __launch_bounds__(256, 2) void ntt_fwd_rows8(NttArgs a, u32 chunks)
     {
         __shared__ __align__(16) u64 lds[RM_TW_WORDS + RM_X_WORDS];
@@ -785,38 +778,39 @@ namespace
         u64 *base = a.data + ((u64)limb << a.log_n) + (size_t)(tile * RM_ROWS + rl) * 256;
         const bool lazy = a.lazy != 0;
 
-        const u32 pairs = (a.n_polys + 1) / 2;
-        u64 xn[2][8];
-        u32 pi = chunk;
-        if (pi < pairs)
-        {
-            const u64 *src[2] = {base + (u64)(2 * pi) * a.poly_stride + t,
-                                 base + (u64)(2 * pi + 1 < a.n_polys ? 2 * pi + 1 : 2 * pi) * a.poly_stride + t};
-            rows8_load<2>(xn, src);
-        }
-        for (; pi < pairs; pi += chunks)
-        {
-            u64 x[2][8];
+        const u32 groups = (a.n_polys + ND - 1) / ND;
+        u64 xn[ND][8];
+        auto request = [&](u32 g) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < ND; ++n)
+            {
+                const u32 poly = ND * g + n < a.n_polys ? ND * g + n : ND * g; // a ragged last group repeats its first
+                const u64 *src = base + (u64)poly * a.poly_stride + t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    xn[n][e] = NT_LOAD(src + e * 32);
+            }
+        };
+        u32 pi = chunk;
+        if (pi < groups)
+            request(pi);
+        for (; pi < groups; pi += chunks)
+        {
+            u64 x[ND][8];
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     x[n][e] = xn[n][e];
-            const u32 nx = pi + chunks;
-            if (nx < pairs)
-            {
-                const u64 *src[2] = {base + (u64)(2 * nx) * a.poly_stride + t,
-                                     base + (u64)(2 * nx + 1 < a.n_polys ? 2 * nx + 1 : 2 * nx) * a.poly_stride + t};
-                rows8_load<2>(xn, src);
-            }
-            rm_rows<2, WIDE>(x, tw, xs, t, q, red_r, red_shift);
-            const bool two = 2 * pi + 1 < a.n_polys;
+            if (pi + chunks < groups)
+                request(pi + chunks);
+            rm_rows<ND, WIDE>(x, tw, xs, t, q, red_r, red_shift);
             // third exchange: from 8 consecutive coefficients per thread to 16-byte pieces that are consecutive
             // across the lanes of a row, so that every store instruction writes whole 512-byte runs
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < ND; ++n)
             {
-                if (n == 1 && !two)
+                if (ND * pi + n >= a.n_polys)
                     break;
                 rm_wave_sync();
 #pragma unroll
@@ -836,7 +830,7 @@ namespace
                     *reinterpret_cast<ulonglong2 *>(xs + ((8 * t + u) ^ (((t >> 1) & 3) << 1))) = v;
                 }
                 rm_wave_sync();
-                u64 *o = base + (u64)(2 * pi + n) * a.poly_stride;
+                u64 *o = base + (u64)(ND * pi + n) * a.poly_stride;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                 {
@@ -988,10 +982,12 @@ namespace
         constexpr int N1 = 1 << LOGN1;
         constexpr int C = TW / N1;
         constexpr int SUB = 16 >> K1;
+        static_assert(TW / 16 >= 256, "stage_col_twiddles copies with the first 256 threads of the workgroup");
+        static_assert((TW + 3 * 256) * sizeof(u64) <= 80 * 1024, "two column workgroups per CU must fit 160 KB of LDS");
         __shared__ u64 lds[TW];
 
         const u32 n = 1u << a.log_n;
-        const Where w = locate(a, blockIdx.x, ROW_LEN / C);
+        const Where w = locate<true>(a, blockIdx.x, ROW_LEN / C);
         if (w.skip)
             return;
         const typename P::Mod m = P::mod(a.mods[w.mod]);
@@ -1216,7 +1212,7 @@ namespace
                     chunks = max_chunks;
                 if (chunks < 1)
                     chunks = 1;
-                hipLaunchKernelGGL(ntt_fwd_rows8<P::WIDE>, dim3((u32)(groups * chunks)), dim3(256), 0, s, a, chunks);
+                hipLaunchKernelGGL((ntt_fwd_rows8<P::WIDE, 2>), dim3((u32)(groups * chunks)), dim3(256), 0, s, a, chunks);
             }
             else
                 hipLaunchKernelGGL((ntt_fwd_rows<P>), dim3((u32)row_blocks), dim3(256), 0, s, a);

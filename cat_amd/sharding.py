@@ -13,6 +13,9 @@ CPU with gloo in tests/test_sharding_gloo.py.
 """
 from __future__ import annotations
 
+import ctypes
+import glob
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -59,6 +62,58 @@ def broadcast_key(key: torch.Tensor, src: int = 0, bucket_bytes: int = 256 << 20
         else:
             dist.broadcast(piece, src=src)
     return key
+
+
+class _NcclUniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * 128)]  # ncclUniqueId, rccl.h
+
+
+class RcclComm:
+    """An RCCL communicator of the library's own (one rank per GPU), for the C ABI's one collective, cat_key_broadcast.
+
+    librccl is bound with ctypes -- the copy PyTorch ships when there is one (the process then holds ONE RCCL, loaded with
+    RTLD_GLOBAL so that libcat_amd.so's dlsym finds the same instance), else /opt/rocm's.  Rank 0 draws the ncclUniqueId
+    and shares it through the process group that already exists (any backend); ncclCommInitRank then connects the
+    ranks over xGMI.  `handle` is the ncclComm_t to pass to Context.key_broadcast.  A one-GPU box can only make a
+    one-rank communicator (RCCL refuses two ranks on one device); the N > 1 path first runs on a multi-GPU node."""
+
+    def __init__(self, world: int, rank: int):
+        self.lib = self._load()
+        uid = _NcclUniqueId()
+        if rank == 0:
+            self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        if world > 1:
+            # the raw 128 bytes of the id (a c_char array read as .value would stop at the first NUL)
+            box = [ctypes.string_at(ctypes.addressof(uid), 128) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctypes.memmove(ctypes.addressof(uid), box[0], 128)
+        self.handle = ctypes.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+        self._check(self.lib.ncclCommInitRank(ctypes.byref(self.handle), world, uid, rank), "ncclCommInitRank")
+        self.world, self.rank = world, rank
+
+    @staticmethod
+    def _load():
+        names = sorted(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")))
+        names += ["librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"]
+        last = None
+        for name in names:
+            try:
+                return ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+            except OSError as e:
+                last = e
+        raise RuntimeError(f"librccl.so is not available: {last}")
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            self.lib.ncclGetErrorString.restype = ctypes.c_char_p
+            raise RuntimeError(f"RCCL error in {what}: {self.lib.ncclGetErrorString(rc).decode()}")
+
+    def close(self):
+        if self.handle:
+            self.lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            self.lib.ncclCommDestroy(self.handle)
+            self.handle = ctypes.c_void_p()
 
 
 def _host_staged(t: torch.Tensor) -> bool:

@@ -16,11 +16,15 @@
  *  - Limb i of a level-L object is reduced modulo primes[i] of the context (context.cu:607-637).
  *  - Every call returns a cat_status, takes an explicit stream (hipStream_t as void*, NULL = default
  *    stream), is asynchronous with respect to the host, never throws and never exits.
+ *  - A call makes the context's device current while it runs and restores the calling thread's current
+ *    device before it returns.
  *  - Error codes mirror the reference's exceptions (evaluator.cpp:2534-2573): CAT_ERR_INVALID_ARG =
  *    std::invalid_argument, CAT_ERR_LOGIC = std::logic_error, CAT_ERR_OUT_OF_RANGE =
  *    std::out_of_range.  cat_last_error() returns the message of the calling thread's last failure.
  *  - Temporaries come from a context-owned device workspace that grows on demand (hipMalloc happens
- *    only when a call needs more than any earlier call; cat_ctx_reserve() pre-sizes it).
+ *    only when a call needs more than any earlier call; cat_ctx_reserve() pre-sizes it).  Growing inside a
+ *    call means a device-wide synchronisation, hipFree and hipMalloc: cat_ctx_workspace_grew() counts those
+ *    events and cat_ctx_set_workspace_strict() turns them into CAT_ERR_LOGIC.
  *  - One context per device and per host thread of control; calls on one context must not overlap.
  */
 #ifndef CAT_AMD_H
@@ -73,6 +77,14 @@ size_t cat_ctx_workspace_bytes(const cat_ctx *ctx);
  * that much once (cat_ctx_reserve) means no later call synchronises, frees or allocates.  The C++ facade does so for
  * batch 1 when it builds a SEALContext. */
 size_t cat_ctx_workspace_need(const cat_ctx *ctx, uint32_t batch);
+/* No counterpart in the reference (its pool allocates silently, gpu_memorypool.h:64-131).  How many times a call had to
+ * grow the workspace itself (each time: hipDeviceSynchronize + hipFree + hipMalloc inside an otherwise asynchronous
+ * call); cat_ctx_reserve does not count.  A caller that reserved cat_ctx_workspace_need(batch) expects this to stay 0. */
+uint64_t cat_ctx_workspace_grew(const cat_ctx *ctx);
+/* on != 0: a call that would have to grow the workspace fails with CAT_ERR_LOGIC ("the workspace would have to grow to
+ * ... bytes") before launching anything, instead of synchronising and reallocating: for callers under HIP graph capture
+ * or with latency budgets.  cat_ctx_reserve still grows it. */
+cat_status cat_ctx_set_workspace_strict(cat_ctx *ctx, int on);
 uint32_t cat_ctx_log_n(const cat_ctx *ctx);
 uint32_t cat_ctx_n_primes(const cat_ctx *ctx);
 /* NTTTables::get_root() (util/ntt.h:101): the minimal primitive 2N-th root used for prime i */
