@@ -8,7 +8,7 @@ HDR := include/cat_amd.h cat_amd/csrc/context.hpp cat_amd/csrc/host_math.hpp cat
 OBJ := $(patsubst cat_amd/csrc/%,build/%.o,$(SRC))
 LIB := cat_amd/lib/libcat_amd.so
 
-all: $(LIB) oracle facade_test random_test modulus_test
+all: $(LIB) oracle facade_test random_test modulus_test latency_facade
 
 $(LIB): $(OBJ)
 	@mkdir -p cat_amd/lib
@@ -40,8 +40,13 @@ modulus_test: tests/cpp/modulus_test
 tests/cpp/modulus_test: tests/cpp/test_modulus.cpp cat_amd/host/seal_hip_modulus.hpp
 	g++ -std=c++17 -O2 -Wall $< -o $@
 
+# single-ciphertext latencies through seal::Evaluator at the reference's published configuration (needs a GPU to run)
+latency_facade: tools/latency_facade
+tools/latency_facade: tools/latency_facade.cpp cat_amd/host/seal_hip.hpp cat_amd/host/seal_hip_crypto.hpp include/cat_amd.h $(LIB)
+	g++ -std=c++17 -O2 -Wall $< -o $@ -Lcat_amd/lib -lcat_amd -Wl,-rpath,'$$ORIGIN/../cat_amd/lib' -Wl,-rpath-link,/opt/rocm/lib
+
 clean:
 	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean facade_test random_test modulus_test
+.PHONY: all oracle clean facade_test random_test modulus_test latency_facade

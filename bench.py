@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--skip-ntt", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU timing (the parity check stays)")
     ap.add_argument("--skip-parity", action="store_true")
+    ap.add_argument("--skip-latency", action="store_true", help="skip the single-ciphertext latency table (N=32768)")
     ap.add_argument("--cpu-reps", type=int, default=10, help="CPU baseline ops per host thread")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = every core this process may use)")
     ap.add_argument("--config5", action="store_true", help="run the BASELINE config 5 leg also at N=1 (193 GB resident)")
@@ -541,6 +542,10 @@ def main():
             print(json.dumps({"error": "NTT round trip mismatch", **result}))
             sys.exit(1)
 
+    # ---- single-ciphertext latencies at the reference's published configuration (CKKS N=32768, 16 primes) ---------
+    if rank == 0 and world == 1 and not args.skip_latency:
+        result["config"]["latency_us"] = latency_table()
+
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
@@ -548,6 +553,43 @@ def main():
         if comm is not None:
             comm.close()
         dist.destroy_process_group()
+
+
+# image.png of the reference (microseconds per call, CKKS N=32768, 16 primes, one ciphertext): the
+# only numbers it publishes.  Other hardware -- context for the table below, not a same-node comparison.
+REFERENCE_PUBLISHED_US = {
+    "SEAL CPU": {"add": 3954, "multiply": 8187, "multiply_plain": 2773, "square": 8269, "relinearize": 175520,
+                 "rescale": 20132, "rotate_vector_one_step": 175741, "rotate_vector_random": 876642,
+                 "complex_conjugate": 174508},
+    "CAT RTX 3090": {"add": 8, "multiply": 34, "multiply_plain": 6, "square": 26, "relinearize": 4216, "rescale": 696,
+                     "rotate_vector_one_step": 4264, "rotate_vector_random": 20084, "complex_conjugate": 4109},
+    "CAT RTX 4090": {"multiply": 15, "multiply_plain": 4, "relinearize": 2472, "rescale": 441,
+                     "rotate_vector_one_step": 2218},
+}
+
+
+def latency_table():
+    """Runs tools/latency_facade (seal::Evaluator of the C++ facade, one ciphertext per call, the loop of the
+    reference's native/examples/6_performance.cpp:348-603) as a child process and returns its medians."""
+    exe = os.path.join(ROOT, "tools", "latency_facade")
+    if not os.path.exists(exe):
+        return {"error": "tools/latency_facade is not built (make latency_facade)"}
+    try:
+        r = subprocess.run([exe, "10"], capture_output=True, text=True, timeout=240)
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # the table is an extra: its failure must not take the bench line with it
+        return {"error": f"tools/latency_facade failed: {e}"}
+    if "error" in rec:
+        return rec
+    return {
+        "workload": rec["workload"],
+        "through": "seal::Evaluator (cat_amd/host/seal_hip.hpp) over the C ABI, default stream",
+        "timing": rec["timing"] + f"; median of {rec['count']} after one warm-up",
+        "evaluator_median_us": rec["evaluator_median_us"],
+        "c_abi_batch1_median_us": rec["c_abi_batch1_median_us"],
+        "workspace_grew": rec["workspace_grew"],
+        "reference_published_us_other_hardware": REFERENCE_PUBLISHED_US,
+    }
 
 
 def config5_leg(args, torch, dist, cat_amd, sharding, to_host, world, rank, local_rank, device, gen, comm=None):

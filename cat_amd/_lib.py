@@ -24,6 +24,7 @@ SIGNATURES = {
     "cat_ctx_workspace_need": (C.c_size_t, [vp, C.c_uint32]),
     "cat_ctx_workspace_bytes": (C.c_size_t, [vp]),
     "cat_ctx_workspace_grew": (C.c_uint64, [vp]),
+    "cat_ctx_set_pool": (C.c_int, [vp, C.c_size_t]),
     "cat_ctx_set_workspace_strict": (C.c_int, [vp, C.c_int]),
     "cat_ctx_log_n": (C.c_uint32, [vp]),
     "cat_ctx_n_primes": (C.c_uint32, [vp]),

