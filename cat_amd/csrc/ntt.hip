@@ -1122,6 +1122,200 @@ namespace
         }
     }
 
+    // ---- N = 4096, 8192 (written for 16384 too): the whole limb-polynomial in ONE workgroup, one trip over HBM ------
+    // A limb of 32 / 64 / 128 KB fits the 160 KB of LDS, so these sizes need no second pass over memory: 16 B per
+    // coefficient of HBM traffic, which is the algorithmic figure (the two-pass form moves 32).  Same butterfly network
+    // and twiddle order as everything else here (dwthandler.h:94-357).  log2 N = K + 12: the forward transform runs
+    // K stages on registers loaded at stride N/16, then three rounds of four stages at strides 256, 16 and 1 inside
+    // blocks of 4096, 256 and 16 coefficients; the inverse is the mirror image.  Between rounds the data goes through
+    // LDS in place (element i at i + i / 16: every access pattern of the three strides is bank-conflict free or 2-way
+    // at worst), one workgroup barrier per round.  N = 16384 would run as 512 threads x 2 sets of 16 coefficients, one
+    // workgroup per CU; it is bit-exact but slower than the two passes (launch_policy) and is not instantiated.  Twiddles come from L2
+    // (workgroups are ordered limb-major: one prime's table at a time).  Fast-family policies only; the Exact policy,
+    // the fused sources and epilogues stay on the two-pass kernels.
+    template <int LOGN>
+    struct OneCfg
+    {
+        static constexpr int N = 1 << LOGN, K = LOGN - 12;
+        static constexpr int THREADS = LOGN == 12 ? 256 : 512;
+        static constexpr int SETS = (N / 16) / THREADS;
+        static constexpr int WAVES = LOGN == 14 ? 2 : 4; // per SIMD: LDS allows 4 / 2 / 1 workgroups per CU
+        static constexpr int LDS_WORDS = N + N / 16;
+    };
+    __device__ __forceinline__ u32 one_pad(u32 i) { return i + (i >> 4); }
+
+    template <class P, int G0>
+    __device__ __forceinline__ void fwd_round16(u64 (&x)[16], const typename P::Table &tw, u32 base, const typename P::Mod &m)
+    {
+        fwd_stage16<P, 0, col_guard<P>(G0 + 0)>(x, tw, base, m);
+        fwd_stage16<P, 1, col_guard<P>(G0 + 1)>(x, tw, base, m);
+        fwd_stage16<P, 2, col_guard<P>(G0 + 2)>(x, tw, base, m);
+        fwd_stage16<P, 3, col_guard<P>(G0 + 3)>(x, tw, base, m);
+    }
+
+    // one in-place round through LDS: 16-point networks at stride S inside blocks of 16 S, global stages G0 .. G0 + 3
+    template <class P, int LOGN, int G0, int S>
+    __device__ __forceinline__ void fwd_one_round(u64 *lds, const typename P::Table &tw, const typename P::Mod &m)
+    {
+        typedef OneCfg<LOGN> C;
+#pragma unroll
+        for (int set = 0; set < C::SETS; ++set)
+        {
+            const u32 v = set * C::THREADS + threadIdx.x, blk = v / S, r = v % S;
+            u64 x[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                x[e] = lds[one_pad(blk * 16 * S + e * S + r)];
+            fwd_round16<P, G0>(x, tw, (C::N >> 4) / S + blk, m);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                lds[one_pad(blk * 16 * S + e * S + r)] = x[e];
+        }
+    }
+
+    template <class P, int LOGN>
+    __global__ __launch_bounds__(OneCfg<LOGN>::THREADS, OneCfg<LOGN>::WAVES) void ntt_fwd_one(NttArgs a)
+    {
+        typedef OneCfg<LOGN> C;
+        constexpr int N = C::N, K = C::K, T = C::THREADS, Q = N / 16;
+        __shared__ u64 lds[C::LDS_WORDS];
+        const Where w = locate(a, blockIdx.x, 1);
+        if (w.skip)
+            return;
+        const typename P::Mod m = P::mod(a.mods[w.mod]);
+        const typename P::Table tw = P::table(a.tw, w.mod, LOGN, false);
+        u64 *p = a.data + w.offset;
+        {
+            u64 x[C::SETS][16];
+#pragma unroll
+            for (int set = 0; set < C::SETS; ++set)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    x[set][e] = p[e * Q + set * T + threadIdx.x];
+#pragma unroll
+            for (int set = 0; set < C::SETS; ++set)
+            {
+                // registers at stride N/16 cover the whole polynomial: its first K stages, or (K = 0) the first full round
+                if (K == 0)
+                    fwd_round16<P, 0>(x[set], tw, 1, m);
+                if (K >= 1)
+                    fwd_stage16<P, 0, col_guard<P>(0)>(x[set], tw, 1, m);
+                if (K >= 2)
+                    fwd_stage16<P, 1, col_guard<P>(1)>(x[set], tw, 1, m);
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    lds[one_pad(e * Q + set * T + threadIdx.x)] = x[set][e];
+            }
+        }
+        __syncthreads();
+        if (K > 0)
+        {
+            fwd_one_round<P, LOGN, K, 256>(lds, tw, m);
+            __syncthreads();
+        }
+        fwd_one_round<P, LOGN, K + 4, 16>(lds, tw, m);
+        __syncthreads();
+        fwd_one_round<P, LOGN, K + 8, 1>(lds, tw, m);
+        __syncthreads();
+        const bool lazy = a.lazy != 0;
+#pragma unroll
+        for (int j = 0; j < N / (2 * T); ++j)
+        {
+            const u32 i = 2 * (j * T + threadIdx.x);
+            ulonglong2 v;
+            v.x = lds[one_pad(i)];
+            v.y = lds[one_pad(i + 1)];
+            v.x = P::finish_fwd(P::WIDE ? guard(v.x, m.K << 1, m.negK << 1) : v.x, m, lazy);
+            v.y = P::finish_fwd(P::WIDE ? guard(v.y, m.K << 1, m.negK << 1) : v.y, m, lazy);
+            *reinterpret_cast<ulonglong2 *>(p + i) = v;
+        }
+    }
+
+    template <class P, int LOGN, int G0, int S>
+    __device__ __forceinline__ void inv_one_round(u64 *lds, const typename P::Table &tw, const typename P::Mod &m)
+    {
+        typedef OneCfg<LOGN> C;
+        constexpr u32 n = C::N;
+#pragma unroll
+        for (int set = 0; set < C::SETS; ++set)
+        {
+            const u32 v = set * C::THREADS + threadIdx.x, blk = v / S, r = v % S;
+            u64 x[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                x[e] = lds[one_pad(blk * 16 * S + e * S + r)];
+            inv_stage16<P, 0, G0 + 0>(x, tw, n - (n >> (G0 + 0)) + 1 + blk * 8, m);
+            inv_stage16<P, 1, G0 + 1>(x, tw, n - (n >> (G0 + 1)) + 1 + blk * 4, m);
+            inv_stage16<P, 2, G0 + 2>(x, tw, n - (n >> (G0 + 2)) + 1 + blk * 2, m);
+            inv_stage16<P, 3, G0 + 3>(x, tw, n - (n >> (G0 + 3)) + 1 + blk * 1, m);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                lds[one_pad(blk * 16 * S + e * S + r)] = x[e];
+        }
+    }
+
+    template <class P, int LOGN>
+    __global__ __launch_bounds__(OneCfg<LOGN>::THREADS, OneCfg<LOGN>::WAVES) void ntt_inv_one(NttArgs a)
+    {
+        typedef OneCfg<LOGN> C;
+        constexpr int N = C::N, K = C::K, T = C::THREADS, Q = N / 16;
+        constexpr u32 n = N;
+        __shared__ u64 lds[C::LDS_WORDS];
+        const Where w = locate(a, blockIdx.x, 1);
+        if (w.skip)
+            return;
+        const typename P::Mod m = P::mod(a.mods[w.mod]);
+        const typename P::Table tw = P::table(a.tw, w.mod, LOGN, true);
+        u64 *p = a.data + w.offset;
+        // out-of-place form (NttFuse::src on an inverse transform): same limb layout, objects src_stride apart
+        const u64 *pin = a.src ? a.src + (u64)w.poly * a.src_stride + ((u64)w.limb << LOGN) : p;
+#pragma unroll
+        for (int j = 0; j < N / (2 * T); ++j)
+        {
+            const u32 i = 2 * (j * T + threadIdx.x);
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(pin + i);
+            lds[one_pad(i)] = v.x;
+            lds[one_pad(i + 1)] = v.y;
+        }
+        __syncthreads();
+        inv_one_round<P, LOGN, 0, 1>(lds, tw, m);
+        __syncthreads();
+        inv_one_round<P, LOGN, 4, 16>(lds, tw, m);
+        __syncthreads();
+        if (K > 0)
+        {
+            inv_one_round<P, LOGN, 8, 256>(lds, tw, m);
+            __syncthreads();
+        }
+        const bool lazy = a.lazy != 0;
+#pragma unroll
+        for (int set = 0; set < C::SETS; ++set)
+        {
+            u64 x[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                x[e] = lds[one_pad(e * Q + set * T + threadIdx.x)];
+            if (K == 0)
+            {
+                // stages 8 .. 11 at stride 256 = N/16: the last one carries n^-1 (dwthandler.h:274-315)
+                inv_stage16<P, 0, 8>(x, tw, n - (n >> 8) + 1, m);
+                inv_stage16<P, 1, 9>(x, tw, n - (n >> 9) + 1, m);
+                inv_stage16<P, 2, 10>(x, tw, n - (n >> 10) + 1, m);
+                inv_last_stage16<P, 3, 11>(x, m);
+            }
+            if (K == 1)
+                inv_last_stage16<P, 3, 12>(x, m);
+            if (K == 2)
+            {
+                inv_stage16<P, 2, 12>(x, tw, n - (n >> 12) + 1, m);
+                inv_last_stage16<P, 3, 13>(x, m);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                p[e * Q + set * T + threadIdx.x] = P::finish_inv(x[e], m, lazy);
+        }
+    }
+
     // forward transforms of large batches (N = 2^16), plain or with the key-switch raise: column tiles twice as wide,
     // 14.7 against 15.1 ms on BASELINE config 2 and -2.7 % on the raise pass of the metric op (same box); 1024-thread
     // tiles of 64 columns measured slower (16.0 ms)
@@ -1178,6 +1372,34 @@ namespace
                 hipLaunchKernelGGL((ntt_small<Q, true>), dim3((u32)n_lp), dim3(threads), 0, s, a);
             else
                 hipLaunchKernelGGL((ntt_small<Q, false>), dim3((u32)n_lp), dim3(threads), 0, s, a);
+            CAT_HIP(hipGetLastError());
+            return CAT_OK;
+        }
+        // N = 4096 and 8192, plain transforms (an inverse one may read another buffer): one trip over HBM.  Same box, 1 GiB
+        // of 55-bit limbs (profiles/r03_ntt_by_ring_size.txt): forward 0.950 -> 0.730 ms at N = 4096 and 0.859 -> 0.758 ms at
+        // N = 8192, inverse 0.835 -> 0.818 and 0.898 -> 0.892 ms.  N = 16384 (128 KB of LDS, one workgroup per CU: its load,
+        // compute and store phases do not overlap with anything) measured 0.980 / 1.147 ms against 0.848 / 0.882 ms for
+        // the two passes and stays on them.
+        if constexpr (std::is_base_of<Fast, P>::value)
+        if (ctx->log_n <= 13 && !first_only && !a.ep_dest && !a.src2 &&
+            (forward ? !a.src : (!a.src || (a.src_kind == 0 && a.limb_group == 1))))
+        {
+            if (n_lp > 0x7fffffffu)
+                return cat::fail(CAT_ERR_LOGIC, "invalid parameters");
+            typedef typename std::conditional<P::WIDE, Fast, P>::type QI; // Wide is a forward policy
+            const dim3 grid((u32)n_lp);
+            if (forward)
+                switch (ctx->log_n)
+                {
+                case 12: hipLaunchKernelGGL((ntt_fwd_one<P, 12>), grid, dim3(OneCfg<12>::THREADS), 0, s, a); break;
+                default: hipLaunchKernelGGL((ntt_fwd_one<P, 13>), grid, dim3(OneCfg<13>::THREADS), 0, s, a); break;
+                }
+            else
+                switch (ctx->log_n)
+                {
+                case 12: hipLaunchKernelGGL((ntt_inv_one<QI, 12>), grid, dim3(OneCfg<12>::THREADS), 0, s, a); break;
+                default: hipLaunchKernelGGL((ntt_inv_one<QI, 13>), grid, dim3(OneCfg<13>::THREADS), 0, s, a); break;
+                }
             CAT_HIP(hipGetLastError());
             return CAT_OK;
         }
