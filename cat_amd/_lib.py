@@ -36,6 +36,7 @@ SIGNATURES = {
     "cat_upload": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "cat_download": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "cat_stream_sync": (C.c_int, [vp, vp]),
+    "cat_copy": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "cat_ntt_forward": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_uint32, C.c_int, vp]),
     "cat_ntt_inverse": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_uint32, C.c_int, vp]),
     "cat_add": (C.c_int, [vp, vp, vp, vp, u32p, C.c_uint32, C.c_uint32, vp]),
@@ -66,6 +67,9 @@ SIGNATURES = {
     "cat_apply_galois": (C.c_int, [vp, vp, vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, vp]),
     "cat_apply_galois_inplace": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_apply_galois_rescale": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, vp]),
+    "cat_rotate_hoisted": (C.c_int, [vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_uint32,
+                                     C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, vp]),
+    "cat_hoisted_key_prepare": (C.c_int, [vp, vp, C.c_uint32, vp, vp]),
     "cat_bfv_multiply": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_bfv_base_Bsk_size": (C.c_uint32, [vp, C.c_uint32]),
     "cat_bfv_base_Bsk": (C.c_int, [vp, C.c_uint32, u64p]),

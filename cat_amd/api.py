@@ -353,5 +353,28 @@ class Context:
                                                  self._p(out, (b, 2, L - 1, self.n)), L, b, self._stream()))
         return out
 
+    def hoisted_key_prepare(self, key, elt, out=None):
+        """cat_hoisted_key_prepare: sigma_elt^-1 applied to every limb of a Galois key ([k-1, 2, k, N]), once per key"""
+        out = torch.empty_like(key) if out is None else out
+        _check(self.lib.cat_hoisted_key_prepare(self.h, self._key(key), elt, self._key(out), self._stream()))
+        return out
+
+    def rotate_hoisted(self, ct, elts, prepared_keys, out=None):
+        """cat_rotate_hoisted: ct [batch, 2, L, N] -> [len(elts), batch, 2, L, N], one output batch per Galois element;
+        prepared_keys[r] = hoisted_key_prepare(key of elts[r], elts[r]).  Not the reference's words (see cat_amd.h):
+        each output decrypts to what apply_galois_inplace's does."""
+        b, _, L, _ = ct.shape
+        r = len(elts)
+        if len(prepared_keys) != r:
+            raise ValueError("one prepared key per Galois element")
+        out = torch.empty((r, b, 2, L, self.n), dtype=torch.int64, device=ct.device) if out is None else out
+        c_elts = (C.c_uint32 * max(r, 1))(*elts)
+        c_keys = (C.c_void_p * max(r, 1))(*[self._key(k) for k in prepared_keys])
+        self._p(out, (r, b, 2, L, self.n))
+        c_outs = (C.c_void_p * max(r, 1))(*[out[i].data_ptr() for i in range(r)])
+        _check(self.lib.cat_rotate_hoisted(self.h, self._p(ct, (b, 2, L, self.n)), c_elts, c_keys, r, c_outs, L, b,
+                                           self._stream()))
+        return out
+
     def rotate_vector(self, ct, step, key):
         return self.apply_galois_inplace(ct, galois_elt_from_step(self.log_n, step), key)

@@ -441,7 +441,10 @@ size_t cat_ctx_workspace_need(const cat_ctx *ctx, uint32_t batch)
     size_t words = 0;
     auto take = [&](size_t w) { words = w > words ? w : words; };
     if (k > 1 && ctx->scheme != CAT_SCHEME_NONE)
+    {
         take(ws_words_galois(N, L, b)); // >= ws_words_switch_key with or without the rescale tail
+        take(ws_words_rotate_hoisted(N, L, b));
+    }
     take(ws_words_rescale(N, k, b * 3)); // a rescale / mod switch may start at the key level
     take(ws_words_mod_drop(N, k, b * 3));
     if (ctx->scheme == CAT_SCHEME_BFV)
@@ -574,6 +577,23 @@ cat_status cat_download(cat_ctx *ctx, void *h_dst, const void *d_src, size_t byt
     if (st != CAT_OK)
         return st;
     CAT_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
+    return CAT_OK;
+}
+
+cat_status cat_copy(cat_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, cat_stream s)
+{
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
+    if (st != CAT_OK)
+        return st;
+    if (bytes == 0)
+        return CAT_OK;
+    if (!d_dst || !d_src)
+        return fail(CAT_ERR_INVALID_ARG, "operand");
+    const char *a = (const char *)d_src, *b = (const char *)d_dst;
+    if (!(a + bytes <= b || b + bytes <= a))
+        return fail(CAT_ERR_INVALID_ARG, "destination must not alias the inputs");
+    CAT_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
     return CAT_OK;
 }
 
@@ -1056,6 +1076,82 @@ cat_status cat_apply_galois(cat_ctx *ctx, const uint64_t *in, uint64_t *out, uin
 
 static cat_status galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, const uint64_t *key, uint32_t L, uint32_t batch,
                                  cat_stream s, uint64_t *rescale_out);
+
+// g^-1 modulo 2N for an odd g (the Galois group of the 2N-th cyclotomic ring)
+static uint32_t galois_inverse(uint32_t elt, uint32_t log_n)
+{
+    const uint64_t m = 2ull << log_n;
+    uint64_t inv = 1, base = elt % m;
+    // the group has exponent N: g^(N-1) = g^-1
+    for (uint64_t e = (m >> 1) - 1; e; e >>= 1)
+    {
+        if (e & 1)
+            inv = inv * base % m;
+        base = base * base % m;
+    }
+    return (uint32_t)inv;
+}
+
+cat_status cat_hoisted_key_prepare(cat_ctx *ctx, const uint64_t *key, uint32_t elt, uint64_t *key_out, cat_stream s)
+{
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
+    if (st != CAT_OK)
+        return st;
+    if (ctx->scheme == CAT_SCHEME_NONE || ctx->k < 2)
+        return fail(CAT_ERR_LOGIC, "keyswitching is not supported by the context");
+    if (!key || !key_out)
+        return fail(CAT_ERR_INVALID_ARG, "Galois key not present");
+    if (key == key_out)
+        return fail(CAT_ERR_INVALID_ARG, "result cannot point to the same value as operand");
+    if ((st = aligned16({ key, key_out })) != CAT_OK)
+        return st;
+    if (!(elt & 1) || elt >= 2 * (uint64_t)ctx->n)
+        return fail(CAT_ERR_INVALID_ARG, "Galois element is not valid");
+    // every limb of the key is in NTT form (kswitchkeys.h:90-101): [k-1][2][k] limbs
+    return launch_galois(ctx, true, (const u64 *)key, (u64 *)key_out, galois_inverse(elt, ctx->log_n), ctx->identity_map(),
+                         ctx->k, (ctx->k - 1) * 2, (hipStream_t)s);
+}
+
+cat_status cat_rotate_hoisted(cat_ctx *ctx, const uint64_t *ct, const uint32_t *elts, const uint64_t *const *keys,
+                              uint32_t n_rot, uint64_t *const *outs, uint32_t L, uint32_t batch, cat_stream s)
+{
+    DeviceScope dev;
+    cat_status st = dev.enter(ctx);
+    if (st != CAT_OK)
+        return st;
+    if (ctx->scheme == CAT_SCHEME_NONE || ctx->k < 2)
+        return fail(CAT_ERR_LOGIC, "keyswitching is not supported by the context");
+    if (!ct || L == 0 || L >= ctx->k || L > CAT_MAX_KEYSWITCH_LIMBS)
+        return fail(CAT_ERR_INVALID_ARG, "encrypted is not valid for encryption parameters");
+    if (n_rot && (!elts || !keys))
+        return fail(CAT_ERR_INVALID_ARG, "Galois key not present");
+    if (n_rot && !outs)
+        return fail(CAT_ERR_INVALID_ARG, "destination is not valid");
+    if ((st = aligned16({ ct })) != CAT_OK)
+        return st;
+    const size_t ctw = (size_t)2 * L * ctx->n;
+    const u64 *in_end = (const u64 *)ct + (size_t)batch * ctw;
+    for (uint32_t r = 0; r < n_rot; ++r)
+    {
+        if (!outs[r])
+            return fail(CAT_ERR_INVALID_ARG, "destination is not valid");
+        if ((st = aligned16({ outs[r] })) != CAT_OK)
+            return st;
+        if (!((const u64 *)outs[r] + (size_t)batch * ctw <= (const u64 *)ct || in_end <= (const u64 *)outs[r]))
+            return fail(CAT_ERR_INVALID_ARG, "destination must not alias the inputs");
+        if (!keys[r])
+            return fail(CAT_ERR_INVALID_ARG, "Galois key not present");
+        if ((st = aligned16({ keys[r] })) != CAT_OK)
+            return st;
+        if (!(elts[r] & 1) || elts[r] >= 2 * (uint64_t)ctx->n)
+            return fail(CAT_ERR_INVALID_ARG, "Galois element is not valid");
+    }
+    if (batch == 0 || n_rot == 0)
+        return CAT_OK;
+    return launch_rotate_hoisted(ctx, (const u64 *)ct, elts, (const u64 *const *)keys, n_rot, (u64 *const *)outs, L, batch,
+                                 (hipStream_t)s);
+}
 
 cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *ct, uint32_t elt, const uint64_t *key, uint32_t L,
                                     uint32_t batch, cat_stream s)

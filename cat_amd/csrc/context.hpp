@@ -111,6 +111,11 @@ namespace cat
     {
         return ws_words_switch_key(N, L, batch, true) + batch * 2 * L * N; // the permuted copy behind the key-switch region
     }
+    inline size_t ws_words_rotate_hoisted(size_t N, size_t L, size_t batch)
+    {
+        // t_target [b][L] | ext [b][L+1][L] | prod, permuted prod [b][2][L+1] each | tmp, permuted ct [b][2][L] each
+        return batch * (L + (L + 1) * L + 4 * (L + 1) + 4 * L) * N;
+    }
     inline size_t ws_words_rescale(size_t N, size_t L, size_t polys)
     {
         return polys * N + 2 * polys * (L - 1) * N; // last | tmp | stage (aliased output)
@@ -209,6 +214,9 @@ namespace cat
     cat_status launch_switch_key(cat_ctx *ctx, u64 *enc, const u64 *target, const u64 *key, uint32_t L, uint32_t batch,
                                  size_t enc_stride, size_t target_stride, hipStream_t s, u64 *rescale_out = nullptr,
                                  size_t out_stride = 0);
+    // hoisted rotations (keyswitch.hip): ct [batch][2][L][N], keys[r] prepared with sigma_g^-1, outs[r] [batch][2][L][N]
+    cat_status launch_rotate_hoisted(cat_ctx *ctx, const u64 *ct, const uint32_t *elts, const u64 *const *keys, uint32_t n_rot,
+                                     u64 *const *outs, uint32_t L, uint32_t batch, hipStream_t s);
     // scratch != nullptr: temporaries come from that caller-provided device block of scratch_bytes bytes instead of the
     // context workspace (the no-allocation entry point, capi.cpp); input and output must then not overlap
     cat_status launch_rescale(cat_ctx *ctx, const u64 *in, u64 *out, uint32_t L, uint32_t size, uint32_t batch,

@@ -664,6 +664,178 @@ namespace
 
 namespace cat
 {
+    // Step 4 of switch_key_inplace (evaluator.cpp:2714-2818): the mod-down of prod [batch][2][d+1][N] (NTT form) into
+    // enc [batch][2][d][N], every branch (CKKS, BFV, BGV); with rescale_out the relinearize + rescale tail.  tmp is
+    // [batch][2][d][N] words of scratch, last [batch][2][2][N] (rescale_out only).  Shared by launch_switch_key and the
+    // hoisted rotations.
+    static cat_status mod_down(cat_ctx *ctx, u64 *prod, u64 *tmp, u64 *last, u64 *enc, size_t enc_stride, uint32_t L,
+                               uint32_t batch, hipStream_t s, u64 *rescale_out, size_t out_stride)
+    {
+        const u32 d = L, k = ctx->k, rns = d + 1, log_n = ctx->log_n;
+        const size_t N = ctx->n;
+        const bool bgv = ctx->scheme == CAT_SCHEME_BGV;
+        const bool ckks = ctx->scheme == CAT_SCHEME_CKKS || bgv;
+        const size_t w_tmp = (size_t)batch * 2 * d * N;
+        const LimbMap ident = ctx->identity_map();
+        LimbMap mp{};
+        mp.id[0] = (unsigned char)(k - 1);
+        // the BGV branch transforms back fully (:2724), the others lazily (:2763)
+        // (with rescale_out the special limb is transformed together with the last limb, below)
+        cat_status st = CAT_OK;
+        if (!rescale_out)
+            st = launch_ntt_ex(ctx, false, prod + (size_t)d * N, mp, 1, batch * 2, !bgv, (u64)rns * N, 1, false, s);
+        if (st != CAT_OK)
+            return st;
+        DownArgs g;
+        g.prod = prod;
+        g.tmp = tmp;
+        g.enc = enc;
+        g.mods = ctx->d_mods;
+        g.inv_mod = ctx->d_inv_mod;
+        g.half_mod = ctx->d_half_mod;
+        g.q_mod = ctx->d_q_mod;
+        g.d = d;
+        g.k = k;
+        g.log_n = log_n;
+        g.lazy_shift = ckks ? 2 : 1;
+        g.enc_stride2 = enc_stride / 2;
+        g.total2 = w_tmp / 2;
+        if (bgv && !rescale_out)
+        {
+            // delta (canonical) by its own kernel, then its forward transform; the subtraction, the product with
+            // P^-1 and the accumulation (:2749-2756) are the same finish step as CKKS, on a lazy transform
+            hipLaunchKernelGGL(ks_down_prepare_bgv_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g,
+                               bgv_args(ctx, k - 1));
+            CAT_HIP(hipGetLastError());
+            if (log_n >= 12)
+            {
+                NttFuse f;
+                f.ep_other = prod;
+                f.ep_other_b = (u64)2 * rns * N;
+                f.ep_other_s = (u64)rns * N;
+                f.ep_dest = enc;
+                f.ep_dest_b = enc_stride;
+                f.ep_dest_s = (u64)d * N;
+                f.ep_S = 2;
+                f.ep_acc = 1;
+                f.ep_qidx = k - 1;
+                return launch_ntt_ex(ctx, true, tmp, ident, d, batch * 2, true, (u64)d * N, 1, false, s, false, &f);
+            }
+            st = launch_ntt(ctx, true, tmp, ident, d, batch * 2, true, s);
+            if (st != CAT_OK)
+                return st;
+            hipLaunchKernelGGL(ks_down_finish_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+            CAT_HIP(hipGetLastError());
+            return CAT_OK;
+        }
+        if (rescale_out)
+        {
+            // relinearize + rescale_to_next with ONE forward transform per remaining limb.  Sequentially
+            //   enc'[j] = enc[j] + (prod[j] - NTT(r1_j)) P^-1,   out[j] = (enc'[j] - NTT(r2_j)) q_last^-1,
+            // r1 = the mod-down round source (from INTT_P of the special limb), r2 = the rescale round source
+            // (from INTT of enc'[d-1], util/rns.cpp:857-878); the transform is linear, so
+            //   out[j] = (enc[j] + prod[j] P^-1 - NTT(r1_j P^-1 + r2_j)) q_last^-1   (mod q_j, canonical).
+            // The last limb first: the rescale needs INTT(enc'[d-1]), and
+            //   INTT(enc'[d-1]) = INTT(enc[d-1] + prod[d-1] P^-1) - r1_{d-1} P^-1
+            // (the forward transform of the correction and this inverse transform cancel), so one batched inverse
+            // transform over {special limb, u = enc[d-1] + prod[d-1] P^-1} feeds both round sources.
+            TailArgs ta;
+            ta.prod = prod;
+            ta.enc = enc;
+            ta.buf = last;
+            ta.mods = ctx->d_mods;
+            ta.inv_mod = ctx->d_inv_mod;
+            ta.half_mod = ctx->d_half_mod;
+            ta.q_mod = ctx->d_q_mod;
+            ta.d = d;
+            ta.k = k;
+            ta.log_n = log_n;
+            ta.enc_stride2 = enc_stride / 2;
+            ta.total2 = (u64)batch * 2 * N / 2;
+            hipLaunchKernelGGL(tail_prepare_kernel, dim3(grid_for(ta.total2)), dim3(256), 0, s, ta);
+            CAT_HIP(hipGetLastError());
+            LimbMap m2{};
+            m2.id[0] = (unsigned char)(k - 1);
+            m2.id[1] = (unsigned char)(d - 1);
+            st = launch_ntt(ctx, false, last, m2, 2, batch * 2, false, s);
+            if (st != CAT_OK)
+                return st;
+            NttFuse g2;
+            if (bgv)
+            {
+                // the same identities with the BGV corrections (bgv_delta; evaluator.cpp:2715-2758,
+                // util/rns.cpp:1203-1246): r1_j = delta_j of the special-prime product, r2_j = delta_j of the
+                // relinearized last limb.  Their sum is written out by its own kernel (the mod-t step does not fit
+                // the round source), the forward transform keeps the two-term epilogue.
+                const BgvArgs ptP = bgv_args(ctx, k - 1), ptL = bgv_args(ctx, d - 1);
+                hipLaunchKernelGGL(tail_last_bgv_kernel, dim3(grid_for(ta.total2)), dim3(256), 0, s, ta, ptP);
+                CAT_HIP(hipGetLastError());
+                const u64 total2 = (u64)batch * 2 * (d - 1) * N / 2;
+                hipLaunchKernelGGL(tail_delta_bgv_kernel, dim3(grid_for(total2)), dim3(256), 0, s, ta, ptP, ptL, tmp,
+                                   total2);
+                CAT_HIP(hipGetLastError());
+            }
+            else
+            {
+                hipLaunchKernelGGL(tail_last_kernel, dim3(grid_for(ta.total2)), dim3(256), 0, s, ta);
+                CAT_HIP(hipGetLastError());
+                // (c) the remaining d-1 limbs: dual source, two-term epilogue
+                g2.src = last;
+                g2.src_stride = (u64)2 * N;
+                g2.src_kind = 1;
+                g2.src_qidx = k - 1;
+                g2.src2 = last + N;
+                g2.src2_stride = (u64)2 * N;
+                g2.src2_qidx = d - 1;
+            }
+            g2.ep_other = enc;
+            g2.ep_other_b = enc_stride;
+            g2.ep_other_s = (u64)d * N;
+            g2.ep_other2 = prod;
+            g2.ep_other2_b = (u64)2 * rns * N;
+            g2.ep_other2_s = (u64)rns * N;
+            g2.ep_qidx2 = k - 1;
+            g2.ep_dest = rescale_out;
+            g2.ep_dest_b = out_stride;
+            g2.ep_dest_s = (u64)(d - 1) * N;
+            g2.ep_S = 2;
+            g2.ep_acc = 0;
+            g2.ep_qidx = d - 1;
+            return launch_ntt_ex(ctx, true, tmp, ident, d - 1, batch * 2, true, (u64)(d - 1) * N, 1, false, s, false, &g2);
+        }
+        if (ckks && log_n >= 12)
+        {
+            // prepare and finish fused into the two passes of the forward transform of tmp (NttFuse)
+            NttFuse f;
+            f.src = prod + (size_t)d * N;
+            f.src_stride = (u64)rns * N;
+            f.src_kind = 1;
+            f.src_qidx = k - 1;
+            f.ep_other = prod;
+            f.ep_other_b = (u64)2 * rns * N;
+            f.ep_other_s = (u64)rns * N;
+            f.ep_dest = enc;
+            f.ep_dest_b = enc_stride;
+            f.ep_dest_s = (u64)d * N;
+            f.ep_S = 2;
+            f.ep_acc = 1;
+            f.ep_qidx = k - 1;
+            return launch_ntt_ex(ctx, true, tmp, ident, d, batch * 2, true, (u64)d * N, 1, false, s, false, &f);
+        }
+        hipLaunchKernelGGL(ks_down_prepare_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+        CAT_HIP(hipGetLastError());
+        if (ckks)
+            st = launch_ntt(ctx, true, tmp, ident, d, batch * 2, true, s);
+        else
+            st = launch_ntt_ex(ctx, false, prod, ident, d, batch * 2, true, (u64)rns * N, 1, false, s);
+        if (st != CAT_OK)
+            return st;
+        hipLaunchKernelGGL(ks_down_finish_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+        CAT_HIP(hipGetLastError());
+
+        return CAT_OK;
+    }
+
     cat_status launch_switch_key(cat_ctx *ctx, u64 *enc, const u64 *target, const u64 *key, uint32_t L, uint32_t batch,
                                  size_t enc_stride, size_t target_stride, hipStream_t s, u64 *rescale_out, size_t out_stride)
     {
@@ -775,162 +947,105 @@ namespace cat
             CAT_HIP(hipGetLastError());
         }
         // step 4
+        return mod_down(ctx, prod, tmp, last, enc, enc_stride, L, batch, s, rescale_out, out_stride);
+    }
+
+    // Hoisted rotations (second half; no counterpart in the reference, whose rotate_internal runs one full
+    // switch_key_inplace per Galois element, evaluator.cpp:2466-2521).  Several Galois elements g_1 .. g_r applied to the
+    // SAME ciphertexts share everything that does not depend on the element: the inverse transform of c1, the modulus
+    // raise and the d (d + 1) forward transforms of the extended digits -- all but a few per cent of a key switch's
+    // arithmetic.  Per element there remain the inner product with that element's key, one permutation of the 2 (d + 1)
+    // product limbs and the mod-down:
+    //     sigma_g(ext_J) * key_J  =  sigma_g( ext_J * sigma_g^-1(key_J) )           (sigma_g permutes NTT-domain values)
+    // so the inner product runs on the extended digits as they lie against the PREPARED key sigma_g^-1(key)
+    // (cat_hoisted_key_prepare, once per key), and its result is permuted afterwards.
+    // Not bit-identical to the reference's un-hoisted rotation, and it cannot be: the reference decomposes sigma_g(c1),
+    // whose negated coefficients have the canonical digits q_J - t, and the residue of q_J - t modulo another prime is not
+    // minus the residue of t; here the digits of c1 are permuted after the decomposition.  Both are key switches of the
+    // same polynomial with digits below q_J (same noise bound); the results decrypt to the same rotated message.
+    cat_status launch_rotate_hoisted(cat_ctx *ctx, const u64 *ct, const uint32_t *elts, const u64 *const *keys, uint32_t n_rot,
+                                     u64 *const *outs, uint32_t L, uint32_t batch, hipStream_t s)
+    {
+        const u32 d = L, k = ctx->k, rns = d + 1, log_n = ctx->log_n;
+        const size_t N = ctx->n, ctw = (size_t)2 * d * N;
+        const bool ckks = ctx->scheme == CAT_SCHEME_CKKS || ctx->scheme == CAT_SCHEME_BGV; // NTT-form ciphertexts
+        const size_t w_target = (size_t)batch * d * N, w_ext = (size_t)batch * rns * d * N, w_prod = (size_t)batch * 2 * rns * N,
+                     w_tmp = (size_t)batch * 2 * d * N;
+        if (w_target + w_ext + 2 * w_prod + 2 * w_tmp != ws_words_rotate_hoisted(N, d, batch))
+            return fail(CAT_ERR_LOGIC, "workspace formula out of step");
+        u64 *ws = (u64 *)workspace(ctx, ws_words_rotate_hoisted(N, d, batch) * sizeof(u64));
+        if (!ws)
+            return workspace_status(ctx);
+        u64 *t_target = ws, *ext = t_target + w_target, *prod = ext + w_ext, *prod2 = prod + w_prod, *tmp = prod2 + w_prod,
+            *perm = tmp + w_tmp;
+        const LimbMap ident = ctx->identity_map();
+        const u64 *c1 = ct + (size_t)d * N;
+        // shared part: steps 1 and 2 of switch_key_inplace on c1 as it lies, every extended digit fully transformed
+        const u64 *coeff_target = c1;
+        size_t coeff_stride = ctw;
+        if (ckks)
         {
-            LimbMap mp{};
-            mp.id[0] = (unsigned char)(k - 1);
-            // the BGV branch transforms back fully (:2724), the others lazily (:2763)
-            // (with rescale_out the special limb is transformed together with the last limb, below)
-            cat_status st = CAT_OK;
-            if (!rescale_out)
-                st = launch_ntt_ex(ctx, false, prod + (size_t)d * N, mp, 1, batch * 2, !bgv, (u64)rns * N, 1, false, s);
+            cat_status st;
+            if (log_n >= 12)
+            {
+                NttFuse in;
+                in.src = c1;
+                in.src_stride = ctw;
+                st = launch_ntt_ex(ctx, false, t_target, ident, d, batch, false, (u64)d * N, 1, false, s, false, &in);
+            }
+            else
+            {
+                CAT_HIP(hipMemcpy2DAsync(t_target, d * N * sizeof(u64), c1, ctw * sizeof(u64), d * N * sizeof(u64), batch,
+                                         hipMemcpyDeviceToDevice, s));
+                st = launch_ntt(ctx, false, t_target, ident, d, batch, false, s);
+            }
             if (st != CAT_OK)
                 return st;
-            DownArgs g;
+            coeff_target = t_target;
+            coeff_stride = (size_t)d * N;
+        }
+        {
+            LimbMap map{};
+            for (u32 I = 0; I < rns; ++I)
+                map.id[I] = (unsigned char)(I == d ? k - 1 : I);
+            NttFuse raise;
+            raise.src = coeff_target;
+            raise.src_stride = coeff_stride;
+            const cat_status st = launch_ntt_ex(ctx, true, ext, map, rns * d, batch, true, (u64)rns * d * N, d, ckks, s, false, &raise);
+            if (st != CAT_OK)
+                return st;
+        }
+        for (uint32_t r = 0; r < n_rot; ++r)
+        {
+            MacArgs g;
+            g.ext = ext;
+            g.target = c1; // the I == J operands (NTT-form schemes): the original limb, as :2635-2638
+            g.key = keys[r];
             g.prod = prod;
-            g.tmp = tmp;
-            g.enc = enc;
             g.mods = ctx->d_mods;
-            g.inv_mod = ctx->d_inv_mod;
-            g.half_mod = ctx->d_half_mod;
-            g.q_mod = ctx->d_q_mod;
             g.d = d;
             g.k = k;
             g.log_n = log_n;
-            g.lazy_shift = ckks ? 2 : 1;
-            g.enc_stride2 = enc_stride / 2;
-            g.total2 = w_tmp / 2;
-            if (bgv && !rescale_out)
-            {
-                // delta (canonical) by its own kernel, then its forward transform; the subtraction, the product with
-                // P^-1 and the accumulation (:2749-2756) are the same finish step as CKKS, on a lazy transform
-                hipLaunchKernelGGL(ks_down_prepare_bgv_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g,
-                                   bgv_args(ctx, k - 1));
-                CAT_HIP(hipGetLastError());
-                if (log_n >= 12)
-                {
-                    NttFuse f;
-                    f.ep_other = prod;
-                    f.ep_other_b = (u64)2 * rns * N;
-                    f.ep_other_s = (u64)rns * N;
-                    f.ep_dest = enc;
-                    f.ep_dest_b = enc_stride;
-                    f.ep_dest_s = (u64)d * N;
-                    f.ep_S = 2;
-                    f.ep_acc = 1;
-                    f.ep_qidx = k - 1;
-                    return launch_ntt_ex(ctx, true, tmp, ident, d, batch * 2, true, (u64)d * N, 1, false, s, false, &f);
-                }
-                st = launch_ntt(ctx, true, tmp, ident, d, batch * 2, true, s);
-                if (st != CAT_OK)
-                    return st;
-                hipLaunchKernelGGL(ks_down_finish_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
-                CAT_HIP(hipGetLastError());
-                return CAT_OK;
-            }
-            if (rescale_out)
-            {
-                // relinearize + rescale_to_next with ONE forward transform per remaining limb.  Sequentially
-                //   enc'[j] = enc[j] + (prod[j] - NTT(r1_j)) P^-1,   out[j] = (enc'[j] - NTT(r2_j)) q_last^-1,
-                // r1 = the mod-down round source (from INTT_P of the special limb), r2 = the rescale round source
-                // (from INTT of enc'[d-1], util/rns.cpp:857-878); the transform is linear, so
-                //   out[j] = (enc[j] + prod[j] P^-1 - NTT(r1_j P^-1 + r2_j)) q_last^-1   (mod q_j, canonical).
-                // The last limb first: the rescale needs INTT(enc'[d-1]), and
-                //   INTT(enc'[d-1]) = INTT(enc[d-1] + prod[d-1] P^-1) - r1_{d-1} P^-1
-                // (the forward transform of the correction and this inverse transform cancel), so one batched inverse
-                // transform over {special limb, u = enc[d-1] + prod[d-1] P^-1} feeds both round sources.
-                TailArgs ta;
-                ta.prod = prod;
-                ta.enc = enc;
-                ta.buf = last;
-                ta.mods = ctx->d_mods;
-                ta.inv_mod = ctx->d_inv_mod;
-                ta.half_mod = ctx->d_half_mod;
-                ta.q_mod = ctx->d_q_mod;
-                ta.d = d;
-                ta.k = k;
-                ta.log_n = log_n;
-                ta.enc_stride2 = enc_stride / 2;
-                ta.total2 = (u64)batch * 2 * N / 2;
-                hipLaunchKernelGGL(tail_prepare_kernel, dim3(grid_for(ta.total2)), dim3(256), 0, s, ta);
-                CAT_HIP(hipGetLastError());
-                LimbMap m2{};
-                m2.id[0] = (unsigned char)(k - 1);
-                m2.id[1] = (unsigned char)(d - 1);
-                st = launch_ntt(ctx, false, last, m2, 2, batch * 2, false, s);
-                if (st != CAT_OK)
-                    return st;
-                NttFuse g2;
-                if (bgv)
-                {
-                    // the same identities with the BGV corrections (bgv_delta; evaluator.cpp:2715-2758,
-                    // util/rns.cpp:1203-1246): r1_j = delta_j of the special-prime product, r2_j = delta_j of the
-                    // relinearized last limb.  Their sum is written out by its own kernel (the mod-t step does not fit
-                    // the round source), the forward transform keeps the two-term epilogue.
-                    const BgvArgs ptP = bgv_args(ctx, k - 1), ptL = bgv_args(ctx, d - 1);
-                    hipLaunchKernelGGL(tail_last_bgv_kernel, dim3(grid_for(ta.total2)), dim3(256), 0, s, ta, ptP);
-                    CAT_HIP(hipGetLastError());
-                    const u64 total2 = (u64)batch * 2 * (d - 1) * N / 2;
-                    hipLaunchKernelGGL(tail_delta_bgv_kernel, dim3(grid_for(total2)), dim3(256), 0, s, ta, ptP, ptL, tmp,
-                                       total2);
-                    CAT_HIP(hipGetLastError());
-                }
-                else
-                {
-                    hipLaunchKernelGGL(tail_last_kernel, dim3(grid_for(ta.total2)), dim3(256), 0, s, ta);
-                    CAT_HIP(hipGetLastError());
-                    // (c) the remaining d-1 limbs: dual source, two-term epilogue
-                    g2.src = last;
-                    g2.src_stride = (u64)2 * N;
-                    g2.src_kind = 1;
-                    g2.src_qidx = k - 1;
-                    g2.src2 = last + N;
-                    g2.src2_stride = (u64)2 * N;
-                    g2.src2_qidx = d - 1;
-                }
-                g2.ep_other = enc;
-                g2.ep_other_b = enc_stride;
-                g2.ep_other_s = (u64)d * N;
-                g2.ep_other2 = prod;
-                g2.ep_other2_b = (u64)2 * rns * N;
-                g2.ep_other2_s = (u64)rns * N;
-                g2.ep_qidx2 = k - 1;
-                g2.ep_dest = rescale_out;
-                g2.ep_dest_b = out_stride;
-                g2.ep_dest_s = (u64)(d - 1) * N;
-                g2.ep_S = 2;
-                g2.ep_acc = 0;
-                g2.ep_qidx = d - 1;
-                return launch_ntt_ex(ctx, true, tmp, ident, d - 1, batch * 2, true, (u64)(d - 1) * N, 1, false, s, false, &g2);
-            }
-            if (ckks && log_n >= 12)
-            {
-                // prepare and finish fused into the two passes of the forward transform of tmp (NttFuse)
-                NttFuse f;
-                f.src = prod + (size_t)d * N;
-                f.src_stride = (u64)rns * N;
-                f.src_kind = 1;
-                f.src_qidx = k - 1;
-                f.ep_other = prod;
-                f.ep_other_b = (u64)2 * rns * N;
-                f.ep_other_s = (u64)rns * N;
-                f.ep_dest = enc;
-                f.ep_dest_b = enc_stride;
-                f.ep_dest_s = (u64)d * N;
-                f.ep_S = 2;
-                f.ep_acc = 1;
-                f.ep_qidx = k - 1;
-                return launch_ntt_ex(ctx, true, tmp, ident, d, batch * 2, true, (u64)d * N, 1, false, s, false, &f);
-            }
-            hipLaunchKernelGGL(ks_down_prepare_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+            g.use_diag = ckks ? 1 : 0;
+            g.target_stride = ctw;
+            g.batch = batch;
+            constexpr int BB = 4;
+            g.total = (u64)((batch + BB - 1) / BB) * rns * (N / 2);
+            if (g.total > 0x7fffffffull * 256)
+                return fail(CAT_ERR_LOGIC, "invalid parameters");
+            hipLaunchKernelGGL(ks_mac_kernel<BB>, dim3((u32)((g.total + 255) / 256)), dim3(256), 0, s, g);
             CAT_HIP(hipGetLastError());
-            if (ckks)
-                st = launch_ntt(ctx, true, tmp, ident, d, batch * 2, true, s);
-            else
-                st = launch_ntt_ex(ctx, false, prod, ident, d, batch * 2, true, (u64)rns * N, 1, false, s);
+            cat_status st = launch_galois(ctx, true, prod, prod2, elts[r], ident, rns, batch * 2, s);
             if (st != CAT_OK)
                 return st;
-            hipLaunchKernelGGL(ks_down_finish_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
-            CAT_HIP(hipGetLastError());
+            // (sigma_g(c0), 0) as apply_galois_inplace leaves it (:2429-2449), then the mod-down adds the switched part
+            u64 *out_r = outs[r];
+            if ((st = launch_galois(ctx, ckks, ct, perm, elts[r], ident, d, batch * 2, s)) != CAT_OK)
+                return st;
+            if ((st = launch_copy_c0_zero_c1(ctx, perm, out_r, d, batch, s)) != CAT_OK)
+                return st;
+            if ((st = mod_down(ctx, prod2, tmp, nullptr, out_r, ctw, d, batch, s, nullptr, 0)) != CAT_OK)
+                return st;
         }
         return CAT_OK;
     }

@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <initializer_list>
 #include <limits>
+#include <map>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -267,10 +268,9 @@ namespace seal
             L_ = o.L_;
             if (o.words())
             {
-                // device-to-device through the staging entry points of the ABI
-                std::vector<std::uint64_t> tmp(o.words());
-                o.download(tmp.data());
-                upload(tmp.data());
+                // device to device on the default stream, in order with the work already queued on either buffer
+                if (cat_copy(ctx_->handle(), d_, o.d_, o.words() * sizeof(std::uint64_t), nullptr) != CAT_OK)
+                    throw std::runtime_error(cat_last_error());
             }
             return *this;
         }
@@ -846,8 +846,34 @@ namespace seal
         {
             return has_index(get_index(galois_elt));
         }
+        ~GaloisKeys() override
+        {
+            for (auto &kv : hoisted_)
+                cat_free(ctx_->handle(), kv.second);
+        }
+        // Not in the reference: the key of galois_elt prepared for hoisted rotations (cat_hoisted_key_prepare: sigma^-1
+        // applied to every limb), made on first use and kept beside the key.  Changing a key with set_key / load after
+        // its first hoisted use is not supported.
+        const std::uint64_t *d_hoisted_key(std::uint32_t galois_elt) const
+        {
+            auto it = hoisted_.find(galois_elt);
+            if (it != hoisted_.end())
+                return it->second;
+            const std::uint64_t *key = d_key(get_index(galois_elt));
+            std::uint64_t *prepared = nullptr;
+            detail::check(cat_malloc(ctx_->handle(), key_words() * 8, (void **)&prepared));
+            const cat_status st = cat_hoisted_key_prepare(ctx_->handle(), key, galois_elt, prepared, nullptr);
+            if (st != CAT_OK)
+            {
+                cat_free(ctx_->handle(), prepared);
+                detail::check(st);
+            }
+            hoisted_[galois_elt] = prepared;
+            return prepared;
+        }
 
     protected:
+        mutable std::map<std::uint32_t, std::uint64_t *> hoisted_;
         std::size_t saved_entries() const override // galois_keys.data().resize(coeff_count), keygenerator.cpp:188
         {
             return ctx_->poly_modulus_degree();
@@ -1242,6 +1268,57 @@ namespace seal
             detail::check(cat_apply_galois_inplace(h(), encrypted.d_data(), galois_elt,
                                                    galois_keys.d_key(GaloisKeys::get_index(galois_elt)),
                                                    (std::uint32_t)encrypted.coeff_modulus_size(), 1, nullptr));
+        }
+
+        // Not in the reference: several Galois elements applied to ONE ciphertext with the
+        // decomposition, the modulus raise and the forward transforms of the extended digits shared (cat_rotate_hoisted).
+        // Every element needs its own key (no NAF chain: a chain is sequential and has nothing to share).  The outputs
+        // decrypt to what apply_galois_inplace's do; they are not its words (cat_amd.h).
+        void apply_galois_hoisted(const Ciphertext &encrypted, const std::vector<std::uint32_t> &galois_elts,
+                                  const GaloisKeys &galois_keys, std::vector<Ciphertext> &destination) const
+        {
+            verify(encrypted, "encrypted");
+            if (!context_.using_keyswitching())
+                throw std::logic_error("encryption parameters do not support batching");
+            if (encrypted.size() > 2)
+                throw std::invalid_argument("encrypted size must be 2");
+            const std::uint32_t L = (std::uint32_t)encrypted.coeff_modulus_size();
+            std::vector<const std::uint64_t *> keys;
+            for (std::uint32_t elt : galois_elts)
+            {
+                if (!(elt & 1) || elt >= 2 * (std::uint64_t)context_.poly_modulus_degree())
+                    throw std::invalid_argument("Galois element is not valid");
+                if (!galois_keys.has_key(elt))
+                    throw std::invalid_argument("Galois key not present");
+                keys.push_back(galois_keys.d_hoisted_key(elt));
+            }
+            std::vector<Ciphertext> result(galois_elts.size());
+            std::vector<std::uint64_t *> outs;
+            for (Ciphertext &c : result)
+            {
+                c.resize(context_, L, 2);
+                c.is_ntt_form() = encrypted.is_ntt_form();
+                c.scale() = encrypted.scale();
+                c.correction_factor() = encrypted.correction_factor();
+                outs.push_back(c.d_data());
+            }
+            detail::check(cat_rotate_hoisted(h(), encrypted.d_data(), galois_elts.data(), keys.data(),
+                                             (std::uint32_t)galois_elts.size(), outs.data(), L, 1, nullptr));
+            destination = std::move(result);
+        }
+        // rotate_vector (CKKS) / rotate_rows (BFV, BGV) by several step counts at once
+        void rotate_hoisted(const Ciphertext &encrypted, const std::vector<int> &steps, const GaloisKeys &galois_keys,
+                            std::vector<Ciphertext> &destination) const
+        {
+            std::vector<std::uint32_t> elts;
+            for (int st : steps)
+            {
+                const std::uint32_t elt = st == 0 ? 0 : cat_galois_elt_from_step(log_n(), st);
+                if (elt == 0)
+                    throw std::invalid_argument(st == 0 ? "a rotation by zero steps has no Galois element" : "step count too large");
+                elts.push_back(elt);
+            }
+            apply_galois_hoisted(encrypted, elts, galois_keys, destination);
         }
 
         // evaluator.h:1195-1237 -> rotate_internal (evaluator.cpp:2466-2521), incl. the NAF fallback

@@ -108,6 +108,9 @@ cat_status cat_free(cat_ctx *ctx, void *d_ptr);
 cat_status cat_ctx_set_pool(cat_ctx *ctx, size_t max_cached_bytes);
 cat_status cat_upload(cat_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, cat_stream s);
 cat_status cat_download(cat_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, cat_stream s);
+/* device-to-device copy of `bytes` bytes (the reference copies a Ciphertext's device shadow the same way,
+ * ciphertext.cuh:284-316); the ranges must not overlap */
+cat_status cat_copy(cat_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, cat_stream s);
 cat_status cat_stream_sync(cat_ctx *ctx, cat_stream s);
 
 /* ---- a1/a2/a13: negacyclic NTT -------------------------------------------------------------------
@@ -258,6 +261,28 @@ cat_status cat_apply_galois_inplace(cat_ctx *ctx, uint64_t *d_ct, uint32_t galoi
  * is scratch afterwards. */
 cat_status cat_apply_galois_rescale(cat_ctx *ctx, uint64_t *d_ct, uint32_t galois_elt, const uint64_t *d_key,
                                     uint64_t *d_out, uint32_t L, uint32_t batch, cat_stream s);
+
+/* ---- f4 ("next" row 4), second half: hoisted rotations ------------------------------------------------
+ * No counterpart in the reference: Evaluator::rotate_internal runs one full switch_key_inplace per Galois element
+ * (evaluator.cpp:2466-2521).  cat_rotate_hoisted applies n_rot Galois elements to the SAME batch of ciphertexts and shares
+ * what does not depend on the element -- the inverse transform of c1, the modulus raise and the d (d + 1) forward
+ * transforms of the extended digits (evaluator.cpp:2604-2654) -- so that each further element costs an inner product, one
+ * permutation of the product and the mod-down.
+ *   d_ct:   batch x 2 x L x N (CKKS / BGV: NTT form, BFV: coefficient form), read only
+ *   d_keys_prepared[r]: device pointer to the key of galois_elts[r] after cat_hoisted_key_prepare (host array of n_rot pointers)
+ *   d_outs[r]: device pointer to the output batch of galois_elts[r], batch x 2 x L x N each (host array of n_rot pointers);
+ *           none may overlap d_ct, and they must not overlap each other
+ * The results are NOT the reference's words: the reference decomposes sigma_g(c1), this call permutes the digits of c1
+ * after the decomposition, and the canonical digits of a negated coefficient (q_J - t) do not reduce to minus the digits'
+ * residues.  Both are key switches with digits below q_J: every output decrypts to what apply_galois_inplace's output
+ * decrypts to, within the key-switching noise (tests/test_gpu_hoisted.py checks exactly that against the oracle). */
+cat_status cat_rotate_hoisted(cat_ctx *ctx, const uint64_t *d_ct, const uint32_t *galois_elts,
+                              const uint64_t *const *d_keys_prepared, uint32_t n_rot, uint64_t *const *d_outs, uint32_t L,
+                              uint32_t batch, cat_stream s);
+/* d_key_out <- sigma_g^-1 applied to every limb of the GaloisKeys entry of galois_elt (same shape, [n_primes-1][2][n_primes][N];
+ * must not alias d_key): sigma_g(ext) * key = sigma_g(ext * sigma_g^-1(key)) lets the hoisted inner product read the
+ * extended digits where they lie.  Once per key. */
+cat_status cat_hoisted_key_prepare(cat_ctx *ctx, const uint64_t *d_key, uint32_t galois_elt, uint64_t *d_key_out, cat_stream s);
 
 /* ---- a12: Evaluator::bfv_multiply, size 2 x 2 -> 3 (evaluator.cpp:395-567) with the BEHZ tool
  * (util/rns.cpp:418-463, 903-1131).  d_x, d_y: batch x 2 x L x N coefficient form; d_out: batch x 3 x L x N. */

@@ -677,6 +677,35 @@ static void test_crypto(scheme_type scheme)
     vec ph((L - 1) * n);
     so_seal_dot_product_ct_sk(oc, L - 1, sk.data(), expr.data(), 2, 1, ph.data());
     EXPECT(result.to_cpu() == ph && result.scale() == delta * delta / (double)primes[L - 1]);
+
+    // hoisted rotations (not in the reference; cat_rotate_hoisted): the same Galois element twice in one call, each
+    // output decrypting to what the un-hoisted rotation decrypts to, up to key-switching noise, and the input untouched
+    {
+        Ciphertext plain_rot;
+        evaluator.apply_galois(c2, elt, galois_keys, plain_rot);
+        const vec before = c2.to_cpu();
+        std::vector<Ciphertext> hoisted;
+        evaluator.apply_galois_hoisted(c2, { elt, elt }, galois_keys, hoisted);
+        EXPECT(hoisted.size() == 2 && c2.to_cpu() == before);
+        EXPECT(hoisted[0].to_cpu() == hoisted[1].to_cpu() && hoisted[0].scale() == c2.scale() && hoisted[0].is_ntt_form());
+        Plaintext pa(context, L), pb(context, L);
+        decryptor.decrypt(plain_rot, pa);
+        decryptor.decrypt(hoisted[0], pb);
+        vec wa = pa.to_cpu(), wb = pb.to_cpu();
+        so_ntt_inverse(wa.data(), so_context_tables(oc, 0), 0);
+        so_ntt_inverse(wb.data(), so_context_tables(oc, 0), 0);
+        bool close = true;
+        for (size_t i = 0; i < n; ++i)
+        {
+            const uint64_t dlt = wa[i] >= wb[i] ? wa[i] - wb[i] : wb[i] - wa[i];
+            close = close && (dlt < (1u << 20) || primes[0] - dlt < (1u << 20));
+        }
+        EXPECT(close);
+        EXPECT(throws<std::invalid_argument>([&] { evaluator.apply_galois_hoisted(c2, { elt + 2 }, galois_keys, hoisted); })); // "Galois key not present"
+        std::vector<Ciphertext> by_step;
+        evaluator.rotate_hoisted(c2, { 1 }, galois_keys, by_step);
+        EXPECT(by_step.size() == 1 && by_step[0].to_cpu() == hoisted[0].to_cpu());
+    }
     so_context_destroy(oc);
 }
 

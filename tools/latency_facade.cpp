@@ -132,12 +132,28 @@ int main(int argc, char **argv)
             const int random_rotation = (int)(rng() & (n / 2 - 1));
             timed("rotate_vector_random", rec, [&] { evaluator.rotate_vector_inplace(e, random_rotation, gal_keys); });
             timed("complex_conjugate", rec, [&] { evaluator.complex_conjugate_inplace(e, gal_keys); });
+            // not in the reference: eight different rotations of one ciphertext with the decomposition shared
+            // (Evaluator::rotate_hoisted -> cat_rotate_hoisted), against the same eight as separate rotate_vector calls
+            const std::vector<int> eight = { 1, 2, 4, 8, 16, 32, 64, 128 };
+            std::vector<Ciphertext> rotated;
+            timed("rotate_hoisted_x8_per_rotation", rec, [&] { evaluator.rotate_hoisted(e, eight, gal_keys, rotated); });
+            timed("rotate_vector_x8_per_rotation", rec, [&] {
+                for (int st : eight)
+                {
+                    Ciphertext r2;
+                    evaluator.rotate_vector(e, st, gal_keys, r2);
+                }
+            });
         }
         // per-call figures as the reference prints them: add / 3, one-step rotation / 2 (6_performance.cpp:573-586)
         for (double &x : t["add"].v)
             x /= 3;
         for (double &x : t["rotate_vector_one_step"].v)
             x /= 2;
+        for (double &x : t["rotate_hoisted_x8_per_rotation"].v)
+            x /= 8;
+        for (double &x : t["rotate_vector_x8_per_rotation"].v)
+            x /= 8;
 
         // ---- the same operations through the C ABI, one ciphertext, device buffers held by the caller ---------------
         std::map<std::string, Series> c;
