@@ -519,13 +519,13 @@ namespace
     }
 
     // Inverse (Gentleman-Sande) local stage S: register gap 1 << S, 8 >> S twiddles tw[root0 + g].
-    template <class P, int S, int G = 0>
+    template <class P, int S, int G = 0, int CHUNK = TW_CHUNK>
     __device__ __forceinline__ void inv_stage16(u64 (&x)[16], const typename P::Table &tw, u32 root0,
                                                 const typename P::Mod &m)
     {
         constexpr int MODE = inv_mode<P>(G);
         constexpr int gap = 1 << S;
-        constexpr int CNT = 8 >> S, CH = CNT < TW_CHUNK ? CNT : TW_CHUNK;
+        constexpr int CNT = 8 >> S, CH = CNT < CHUNK ? CNT : CHUNK; // twiddles are fetched CH at a time
 #pragma unroll
         for (int g0 = 0; g0 < CNT; g0 += CH)
         {
@@ -1140,9 +1140,18 @@ namespace
         static constexpr int THREADS = LOGN == 12 ? 256 : 512;
         static constexpr int SETS = (N / 16) / THREADS;
         static constexpr int WAVES = LOGN == 14 ? 2 : 4; // per SIMD: LDS allows 4 / 2 / 1 workgroups per CU
+        // the inverse kernel at N = 4096 spills 7 registers at 128 (a spill is HBM traffic): three workgroups per CU instead
+        static constexpr int WAVES_INV = LOGN == 12 ? 3 : WAVES;
         static constexpr int LDS_WORDS = N + N / 16;
     };
     __device__ __forceinline__ u32 one_pad(u32 i) { return i + (i >> 4); }
+    // padded LDS position of element e of a 16-point network at stride S (S = 1 or a multiple of 16) whose element 0 is
+    // `first`: linear in e, so the sixteen accesses of a thread share one address register
+    template <int S>
+    __device__ __forceinline__ u32 one_at(u32 first_padded, int e)
+    {
+        return first_padded + e * (S == 1 ? 1 : S + S / 16);
+    }
 
     template <class P, int G0>
     __device__ __forceinline__ void fwd_round16(u64 (&x)[16], const typename P::Table &tw, u32 base, const typename P::Mod &m)
@@ -1162,14 +1171,15 @@ namespace
         for (int set = 0; set < C::SETS; ++set)
         {
             const u32 v = set * C::THREADS + threadIdx.x, blk = v / S, r = v % S;
+            const u32 at = one_pad(blk * 16 * S + r); // element e: blk * 16 S + e S + r
             u64 x[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                x[e] = lds[one_pad(blk * 16 * S + e * S + r)];
+                x[e] = lds[one_at<S>(at, e)];
             fwd_round16<P, G0>(x, tw, (C::N >> 4) / S + blk, m);
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                lds[one_pad(blk * 16 * S + e * S + r)] = x[e];
+                lds[one_at<S>(at, e)] = x[e];
         }
     }
 
@@ -1204,7 +1214,7 @@ namespace
                     fwd_stage16<P, 1, col_guard<P>(1)>(x[set], tw, 1, m);
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    lds[one_pad(e * Q + set * T + threadIdx.x)] = x[set][e];
+                    lds[one_at<Q>(one_pad(set * T + threadIdx.x), e)] = x[set][e];
             }
         }
         __syncthreads();
@@ -1240,22 +1250,25 @@ namespace
         for (int set = 0; set < C::SETS; ++set)
         {
             const u32 v = set * C::THREADS + threadIdx.x, blk = v / S, r = v % S;
+            const u32 at = one_pad(blk * 16 * S + r);
             u64 x[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                x[e] = lds[one_pad(blk * 16 * S + e * S + r)];
-            inv_stage16<P, 0, G0 + 0>(x, tw, n - (n >> (G0 + 0)) + 1 + blk * 8, m);
+                x[e] = lds[one_at<S>(at, e)];
+            // the first stage's eight twiddles in two fetches of four: with eight at once these kernels spill a few
+            // registers at 128 VGPRs, and spills are HBM traffic (PMC: 1.22 x algorithmic instead of 1.03 x)
+            inv_stage16<P, 0, G0 + 0, 4>(x, tw, n - (n >> (G0 + 0)) + 1 + blk * 8, m);
             inv_stage16<P, 1, G0 + 1>(x, tw, n - (n >> (G0 + 1)) + 1 + blk * 4, m);
             inv_stage16<P, 2, G0 + 2>(x, tw, n - (n >> (G0 + 2)) + 1 + blk * 2, m);
             inv_stage16<P, 3, G0 + 3>(x, tw, n - (n >> (G0 + 3)) + 1 + blk * 1, m);
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                lds[one_pad(blk * 16 * S + e * S + r)] = x[e];
+                lds[one_at<S>(at, e)] = x[e];
         }
     }
 
     template <class P, int LOGN>
-    __global__ __launch_bounds__(OneCfg<LOGN>::THREADS, OneCfg<LOGN>::WAVES) void ntt_inv_one(NttArgs a)
+    __global__ __launch_bounds__(OneCfg<LOGN>::THREADS, OneCfg<LOGN>::WAVES_INV) void ntt_inv_one(NttArgs a)
     {
         typedef OneCfg<LOGN> C;
         constexpr int N = C::N, K = C::K, T = C::THREADS, Q = N / 16;
@@ -1294,11 +1307,11 @@ namespace
             u64 x[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                x[e] = lds[one_pad(e * Q + set * T + threadIdx.x)];
+                x[e] = lds[one_at<Q>(one_pad(set * T + threadIdx.x), e)];
             if (K == 0)
             {
                 // stages 8 .. 11 at stride 256 = N/16: the last one carries n^-1 (dwthandler.h:274-315)
-                inv_stage16<P, 0, 8>(x, tw, n - (n >> 8) + 1, m);
+                inv_stage16<P, 0, 8, 4>(x, tw, n - (n >> 8) + 1, m);
                 inv_stage16<P, 1, 9>(x, tw, n - (n >> 9) + 1, m);
                 inv_stage16<P, 2, 10>(x, tw, n - (n >> 10) + 1, m);
                 inv_last_stage16<P, 3, 11>(x, m);

@@ -111,3 +111,54 @@ def test_calls_leave_the_current_device_as_it_was(cat, oracle):
     ctx.ntt_inverse(x)
     ctx.close()
     assert torch.cuda.current_device() == before
+
+
+def test_block_pool_hands_freed_blocks_out_again(cat, oracle):
+    """cat_ctx_set_pool (gpu_memorypool.h:64-131 in the reference): with the pool on, cat_free keeps a block and the next
+    cat_malloc of exactly that size gets it back; other sizes and a pool over its limit go to hipMalloc / hipFree."""
+    import ctypes as C
+
+    primes = list(reversed(oracle.get_primes(2 * 1024, 40, 2)))
+    ctx = cat.Context(10, primes, cat.SCHEME_CKKS)
+    lib, h = ctx.lib, ctx.h
+
+    def malloc(nbytes):
+        p = C.c_void_p()
+        assert lib.cat_malloc(h, nbytes, C.byref(p)) == 0
+        return p
+
+    assert lib.cat_ctx_set_pool(h, 1 << 20) == 0
+    a = malloc(65536)
+    addr = a.value
+    assert lib.cat_free(h, a) == 0
+    b = malloc(65536)
+    assert b.value == addr                     # the kept block
+    c = malloc(65536)
+    assert c.value != addr                     # nothing kept any more: a fresh block
+    d = malloc(131072)
+    assert lib.cat_free(h, b) == 0 and lib.cat_free(h, c) == 0 and lib.cat_free(h, d) == 0
+    big = malloc(2 << 20)                      # larger than the pool's limit: really freed
+    assert lib.cat_free(h, big) == 0
+    assert lib.cat_ctx_set_pool(h, 0) == 0     # releases what is held; cat_free = hipFree again
+    e = malloc(65536)
+    assert lib.cat_free(h, e) == 0
+    ctx.close()
+
+
+def test_copy_is_device_to_device_and_refuses_overlap(cat, oracle):
+    import ctypes as C
+
+    import torch
+
+    primes = list(reversed(oracle.get_primes(2 * 1024, 40, 2)))
+    ctx = cat.Context(10, primes, cat.SCHEME_CKKS)
+    x = torch.arange(4096, dtype=torch.int64, device="cuda")
+    y = torch.zeros_like(x)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert ctx.lib.cat_copy(ctx.h, C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), x.numel() * 8, s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    assert ctx.lib.cat_copy(ctx.h, C.c_void_p(x.data_ptr() + 64), C.c_void_p(x.data_ptr()), 1024, s) == 1
+    assert b"alias" in ctx.lib.cat_last_error()
+    assert ctx.lib.cat_copy(ctx.h, None, None, 0, s) == 0
+    ctx.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Forward / inverse NTT times by ring size (N = 4096 ... 32768), plain batched transforms of ~1 GB.
-Usage: ntt_sizes.py  (CAT_NTT_TWO_PASS=1 forces the two-pass kernels, while that switch exists)"""
+Usage: ntt_sizes.py [log_n ...]"""
 import os
 import sys
 
@@ -11,7 +11,7 @@ import torch
 import cat_amd
 from bench import get_primes_desc
 
-for log_n in (12, 13, 14, 15):
+for log_n in ([int(a) for a in sys.argv[1:]] or (12, 13, 14, 15)):
     n = 1 << log_n
     limbs = 16
     primes = get_primes_desc(2 * n, 55, limbs)
