@@ -48,3 +48,27 @@ def test_key_broadcast_single_rank_communicator_and_no_comm():
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
     ctx.close()
+
+
+def test_bench_communicator_class_on_one_rank():
+    """cat_amd.sharding.RcclComm (what bench.py --gpus N hands to cat_key_broadcast): world size 1 needs no process group;
+    the handle it makes is a valid ncclComm_t for the C ABI's collective, which binds the SAME RCCL instance (dlsym of the
+    copy loaded RTLD_GLOBAL here before any of its own).  The N > 1 exchange needs a multi-GPU node."""
+    import bench
+    from cat_amd import sharding
+
+    n, log_n = 4096, 12
+    primes = list(reversed(bench.get_primes_desc(2 * n, 50, 3)))
+    ctx = cat_amd.Context(log_n, primes, cat_amd.SCHEME_CKKS, device=0)
+    comm = sharding.RcclComm(1, 0)
+    try:
+        gen = torch.Generator(device="cuda:0")
+        gen.manual_seed(2)
+        key = torch.randint(0, min(primes), (2, 2, 3, n), dtype=torch.int64, device="cuda:0", generator=gen)
+        ref = key.clone()
+        ctx.key_broadcast(key, comm.handle, root=0)
+        torch.cuda.synchronize()
+        assert torch.equal(key, ref)
+    finally:
+        comm.close()
+    ctx.close()
