@@ -46,3 +46,20 @@ def test_a_failing_rank_fails_the_launcher():
                        text=True, timeout=120)
     assert r.returncode == 3
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_under_an_external_launcher_gpus_defaults_to_world_size():
+    # `torchrun --nproc-per-node 2 bench.py` without --gpus: the launcher's WORLD_SIZE is adopted
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--launcher-selftest"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0])["n_gpus"] == 2
