@@ -45,6 +45,7 @@ def test_reserved_need_covers_every_entry_point_at_every_level(cat, oracle, sche
     ctx.set_workspace_strict(True)
     key = _uniform(torch, primes, (k - 1, 2), n, 7)
     elt = cat.galois_elt_from_step(log_n, 1)
+    prepared = ctx.hoisted_key_prepare(key, elt)
     for L in range(k - 1, 0, -1):
         x = _uniform(torch, primes[:L], (batch, 2), n, 10 + L)
         y = _uniform(torch, primes[:L], (batch, 2), n, 20 + L)
@@ -59,6 +60,7 @@ def test_reserved_need_covers_every_entry_point_at_every_level(cat, oracle, sche
         ctx.relinearize(prod.clone(), key)
         ctx.switch_key(x.clone(), y[:, 0].contiguous(), key)
         ctx.apply_galois_inplace(x.clone(), elt, key)
+        ctx.rotate_hoisted(x, [elt, elt], [prepared, prepared])
         if L >= 2:
             ctx.relinearize_rescale(prod.clone(), key)
             ctx.apply_galois_rescale(x.clone(), elt, key)
