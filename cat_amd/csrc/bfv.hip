@@ -34,8 +34,26 @@ namespace
         u64 in_stride, out_stride; // words between consecutive polys
         u32 out_off, mt_limb;
         u64 total; // polys * N
+        // fused tail (template parameter EP of bconv_kernel); constants are per OUTPUT limb
+        const MulOp *ep_c0, *ep_c1;
+        const u64 *ep_in; // EP 2: the Bsk part of the input, [polys][..][N]
+        u64 ep_in_stride;
+        u64 ep_k0;        // EP 1: -q^-1 mod m_tilde
+        MulOp ep_k1;      // EP 3: B^-1 mod m_sk
+        u32 ep_msk_id;    // EP 3: modulus id of m_sk; its matrix row follows the osz output rows, its input limb the isz read
     };
 
+    // EP: what happens to each converted residue v before it is stored -- the tails the reference runs as separate loops
+    // over the same coefficients, each needing only values this thread already holds:
+    //   0  out = v (and the residue modulo m_tilde when mt_matrix is given: fastbconv_m_tilde, rns.cpp:1092-1131)
+    //   1  sm_mrq (rns.cpp:981-1041) on top of fastbconv_m_tilde: r = v_mt * (-q^-1) mod m_tilde, centred;
+    //        out_i = (r * (q mod m_i) + v_i) * m_tilde^-1 mod m_i                  ep_c0 = q mod m_i, ep_c1 = m_tilde^-1 mod m_i
+    //   2  fast_floor tail (rns.cpp:1070-1088): out_i = (in_Bsk_i [* t] + (m_i - v_i)) * q^-1 mod m_i
+    //                                                                              ep_c0 = q^-1 mod m_i, ep_c1 = t mod m_i or null
+    //   3  fastbconv_sk tail (rns.cpp:930-977): alpha = (v_sk + (m_sk - in_sk)) * B^-1 mod m_sk, centred;
+    //        out_i = v_i + (alpha > m_sk/2 ? (m_sk - alpha) * (B mod q_i) : alpha * (-B mod q_i))      ep_c0 = B, ep_c1 = -B
+    // Same values as the separate kernels (cat_sm_mrq keeps the standalone form); one write instead of write + read + write.
+    template <int EP>
     __global__ __launch_bounds__(256) void bconv_kernel(BconvArgs g)
     {
         extern __shared__ u64 stage[]; // [isz][256]
@@ -54,6 +72,66 @@ namespace
             stage[j * 256 + threadIdx.x] = mul_shoup(x, g.inv_punc[j].op, g.inv_punc[j].quo, q);
         }
         u64 *dst = g.out + p * g.out_stride + c;
+        u64 mt_r = 0, alpha = 0;
+        bool alpha_neg = false;
+        if (EP == 1)
+        {
+            u64 acc = 0;
+            for (u32 j = 0; j < g.isz; ++j)
+                acc += stage[j * 256 + threadIdx.x] * g.mt_matrix[j];
+            mt_r = ((acc & (MT - 1)) * g.ep_k0) & (MT - 1);
+        }
+        if (EP == 3)
+        {
+            const DevMod m = g.mods[g.ep_msk_id];
+            const u64 *row = g.matrix + (u64)g.osz * g.isz;
+            Acc acc;
+            acc.lo = acc.hi = 0;
+            acc.cc = 0;
+            u32 j = 0;
+            for (; j + 2 <= g.isz; j += 2)
+            {
+                u64 mid;
+                rm_mac2(acc, mid, stage[j * 256 + threadIdx.x], row[j], stage[(j + 1) * 256 + threadIdx.x], row[j + 1]);
+                rm_fold(acc, mid);
+            }
+            if (j < g.isz)
+            {
+                u64 mid = 0;
+                rm_mac(acc, mid, stage[j * 256 + threadIdx.x], row[j]);
+                rm_fold(acc, mid);
+            }
+            const u64 conv_sk = barrett128(acc.lo, acc.hi + acc.cc, m.q, m.ratio0, m.ratio1);
+            const u64 in_sk = src[(u64)g.isz << g.log_n];
+            alpha = mul_shoup(conv_sk + (m.q - in_sk), g.ep_k1.op, g.ep_k1.quo, m.q);
+            alpha_neg = alpha > (m.q >> 1);
+            if (alpha_neg)
+                alpha = m.q - alpha;
+        }
+        // v: canonical residue modulo output prime o
+        auto finish = [&](u32 o, u64 v, u64 q) -> u64 {
+            if (EP == 1)
+            {
+                u64 t = mt_r;
+                if (t >= (MT >> 1))
+                    t += q - MT;
+                const u64 a = mul_shoup(t, g.ep_c0[o].op, g.ep_c0[o].quo, q);
+                return mul_shoup(add_mod(a, v, q), g.ep_c1[o].op, g.ep_c1[o].quo, q);
+            }
+            if (EP == 2)
+            {
+                u64 x = g.ep_in[p * g.ep_in_stride + ((u64)o << g.log_n) + c];
+                if (g.ep_c1)
+                    x = mul_shoup(x, g.ep_c1[o].op, g.ep_c1[o].quo, q);
+                return mul_shoup(x + (q - v), g.ep_c0[o].op, g.ep_c0[o].quo, q);
+            }
+            if (EP == 3)
+            {
+                const MulOp w = alpha_neg ? g.ep_c0[o] : g.ep_c1[o];
+                return add_mod(mul_shoup(alpha, w.op, w.quo, q), v, q);
+            }
+            return v;
+        };
         u32 o = 0;
         // four output residues at a time: one read of the staged residues serves four dot products, and their folds go
         // through rm_fold4 (3 instructions per accumulator instead of the compiler's 8)
@@ -90,7 +168,8 @@ namespace
             for (int k = 0; k < 4; ++k)
             {
                 const DevMod m = g.mods[g.omap.id[o + k]];
-                dst[(u64)(g.out_off + o + k) << g.log_n] = barrett128(acc[k].lo, acc[k].hi + acc[k].cc, m.q, m.ratio0, m.ratio1);
+                dst[(u64)(g.out_off + o + k) << g.log_n] =
+                    finish(o + k, barrett128(acc[k].lo, acc[k].hi + acc[k].cc, m.q, m.ratio0, m.ratio1), m.q);
             }
         }
         for (; o < g.osz; ++o)
@@ -114,9 +193,9 @@ namespace
                 rm_mac(acc, mid, stage[j * 256 + threadIdx.x], row[j]);
                 rm_fold(acc, mid);
             }
-            dst[(u64)(g.out_off + o) << g.log_n] = barrett128(acc.lo, acc.hi + acc.cc, m.q, m.ratio0, m.ratio1);
+            dst[(u64)(g.out_off + o) << g.log_n] = finish(o, barrett128(acc.lo, acc.hi + acc.cc, m.q, m.ratio0, m.ratio1), m.q);
         }
-        if (g.mt_matrix)
+        if (EP == 0 && g.mt_matrix)
         {
             u64 acc = 0;
             for (u32 j = 0; j < g.isz; ++j)
@@ -161,55 +240,6 @@ namespace
         const u64 a = mul_shoup(t, g.c0[j].op, g.c0[j].quo, m.q);
         const u64 b = barrett64(src[(u64)j << g.log_n], m.q, m.ratio1);
         g.out[p * g.out_stride + ((u64)j << g.log_n) + c] = mul_shoup(add_mod(a, b, m.q), g.c1[j].op, g.c1[j].quo, m.q);
-    }
-
-    // fast_floor tail (rns.cpp:1070-1088): conv = FastBConv_{q->Bsk}(in_q) already sits in `out`;
-    //   out_i = (in_Bsk_i [* t] + (m_i - conv_i)) * q^-1 mod m_i       c0 = q^-1 mod m_i, c1 = t mod m_i or null
-    // `in` points at the Bsk part of the input.
-    __global__ __launch_bounds__(256) void floor_finish_kernel(PieceArgs g)
-    {
-        const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-        if (i >= g.total)
-            return;
-        const u32 c = (u32)(i & ((1u << g.log_n) - 1));
-        const u64 r = i >> g.log_n;
-        const u32 j = (u32)(r % g.n_limbs);
-        const u64 p = r / g.n_limbs;
-        const u64 q = g.mods[g.map.id[j]].q;
-        u64 x = g.in[p * g.in_stride + ((u64)j << g.log_n) + c];
-        if (g.c1)
-            x = mul_shoup(x, g.c1[j].op, g.c1[j].quo, q);
-        u64 *o = g.out + p * g.out_stride + ((u64)j << g.log_n) + c;
-        *o = mul_shoup(x + (q - *o), g.c0[j].op, g.c0[j].quo, q);
-    }
-
-    // fastbconv_sk tail (rns.cpp:930-977): `out` holds [polys][L + 1][N]: FastBConv_{B->q} in limbs 0..L-1
-    // and FastBConv_{B->m_sk} in limb L (aux_limb); in_sk is limb |B| of the input.
-    //   alpha = (conv_sk + (m_sk - in_sk)) * B^-1 mod m_sk                         k1 = B^-1 mod m_sk
-    //   alpha > m_sk/2 ? out_i += (m_sk - alpha) * (B mod q_i) : out_i += alpha * (-B mod q_i)   c0 = B, c1 = -B
-    // result -> res [polys][L][N]
-    __global__ __launch_bounds__(256) void sk_finish_kernel(PieceArgs g, u64 *res, u64 res_stride, u32 in_sk_limb,
-                                                             u32 msk_id)
-    {
-        const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-        if (i >= g.total)
-            return;
-        const u32 c = (u32)(i & ((1u << g.log_n) - 1));
-        const u64 r = i >> g.log_n;
-        const u32 j = (u32)(r % g.n_limbs);
-        const u64 p = r / g.n_limbs;
-        const u64 msk = g.mods[msk_id].q;
-        const u64 q = g.mods[g.map.id[j]].q;
-        const u64 *conv = g.out + p * g.out_stride + c;
-        const u64 in_sk = g.in[p * g.in_stride + ((u64)in_sk_limb << g.log_n) + c];
-        const u64 alpha = mul_shoup(conv[(u64)g.aux_limb << g.log_n] + (msk - in_sk), g.k1.op, g.k1.quo, msk);
-        const u64 cur = barrett64(conv[(u64)j << g.log_n], q, g.mods[g.map.id[j]].ratio1);
-        u64 v;
-        if (alpha > (msk >> 1))
-            v = mul_shoup(neg_mod(alpha, msk), g.c0[j].op, g.c0[j].quo, q);
-        else
-            v = mul_shoup(alpha, g.c1[j].op, g.c1[j].quo, q);
-        res[p * res_stride + ((u64)j << g.log_n) + c] = add_mod(v, cur, q);
     }
 
     // (x0,x1) (x) (y0,y1) over an arbitrary limb list; inputs may be lazy (< 4q): evaluator.cpp:497-541
@@ -450,9 +480,30 @@ namespace
         return CAT_OK;
     }
 
-    // FastBConv q -> Bsk (+ m_tilde when mt_limb_valid): in [polys][in_limbs][N] -> out limbs 0..Bsk-1 (+ Bsk)
+    cat_status launch_bconv(const BconvArgs &g, int ep, hipStream_t s)
+    {
+        if (g.total == 0)
+            return CAT_OK;
+        const dim3 grid(blocks_for(g.total)), block(256);
+        const size_t lds = g.isz * 256 * sizeof(u64);
+        switch (ep)
+        {
+        case 0: hipLaunchKernelGGL(bconv_kernel<0>, grid, block, lds, s, g); break;
+        case 1: hipLaunchKernelGGL(bconv_kernel<1>, grid, block, lds, s, g); break;
+        case 2: hipLaunchKernelGGL(bconv_kernel<2>, grid, block, lds, s, g); break;
+        default: hipLaunchKernelGGL(bconv_kernel<3>, grid, block, lds, s, g); break;
+        }
+        CAT_HIP(hipGetLastError());
+        return CAT_OK;
+    }
+
+    // FastBConv q -> Bsk: in [polys][in_limbs][N] -> out limbs 0..Bsk-1
+    //   ep 0: plain (+ the residue modulo m_tilde in limb Bsk when with_mt: fastbconv_m_tilde)
+    //   ep 1: fastbconv_m_tilde followed by sm_mrq, out [polys][Bsk][N] (evaluator.cpp:466-474 as one pass)
+    //   ep 2: fast_floor (rns.cpp:1043-1090): in_B = the Bsk part of the input; times_t multiplies both parts by t first
     cat_status conv_q_to_Bsk(cat_ctx *ctx, const BfvLevel &lv, const u64 *in, u64 in_stride, u64 *out, u64 out_stride,
-                             const MulOp *premul, bool with_mt, u64 polys, hipStream_t s)
+                             const MulOp *premul, bool with_mt, u64 polys, hipStream_t s, int ep = 0,
+                             const u64 *in_B = nullptr, u64 in_B_stride = 0, bool times_t = false)
     {
         BconvArgs g{};
         g.in = in;
@@ -461,7 +512,7 @@ namespace
         g.premul = premul;
         g.inv_punc = ops_at(lv, lv.o_inv_punc_q);
         g.matrix = lv.d_blob + lv.o_q_to_Bsk;
-        g.mt_matrix = with_mt ? lv.d_blob + lv.o_q_to_mt : nullptr;
+        g.mt_matrix = with_mt || ep == 1 ? lv.d_blob + lv.o_q_to_mt : nullptr;
         g.imap = lv.map_q;
         g.omap = lv.map_Bsk;
         g.isz = lv.L;
@@ -472,11 +523,20 @@ namespace
         g.out_off = 0;
         g.mt_limb = lv.Bsk;
         g.total = polys << ctx->log_n;
-        if (g.total == 0)
-            return CAT_OK;
-        hipLaunchKernelGGL(bconv_kernel, dim3(blocks_for(g.total)), dim3(256), g.isz * 256 * sizeof(u64), s, g);
-        CAT_HIP(hipGetLastError());
-        return CAT_OK;
+        if (ep == 1)
+        {
+            g.ep_c0 = ops_at(lv, lv.o_prod_q_Bsk);
+            g.ep_c1 = ops_at(lv, lv.o_inv_mt_Bsk);
+            g.ep_k0 = lv.neg_inv_q_mt;
+        }
+        else if (ep == 2)
+        {
+            g.ep_c0 = ops_at(lv, lv.o_inv_q_Bsk);
+            g.ep_c1 = times_t ? ops_at(lv, lv.o_t_Bsk) : nullptr;
+            g.ep_in = in_B;
+            g.ep_in_stride = in_B_stride;
+        }
+        return launch_bconv(g, ep, s);
     }
 
     cat_status run_sm_mrq(cat_ctx *ctx, const BfvLevel &lv, const u64 *in, u64 in_stride, u64 *out, u64 out_stride,
@@ -502,75 +562,38 @@ namespace
         return CAT_OK;
     }
 
-    // in_q / in_B: the q part and the Bsk part of the input (each with its own poly stride)
+    // in_q / in_B: the q part and the Bsk part of the input (each with its own poly stride); `out` must not overlap in_B
     cat_status run_fast_floor(cat_ctx *ctx, const BfvLevel &lv, const u64 *in_q, u64 in_q_stride, const u64 *in_B,
                               u64 in_B_stride, u64 *out, u64 out_stride, bool times_t, u64 polys, hipStream_t s)
     {
-        cat_status st = conv_q_to_Bsk(ctx, lv, in_q, in_q_stride, out, out_stride,
-                                      times_t ? ops_at(lv, lv.o_t_q) : nullptr, false, polys, s);
-        if (st != CAT_OK)
-            return st;
-        PieceArgs g{};
-        g.in = in_B;
-        g.out = out;
-        g.mods = ctx->d_mods;
-        g.c0 = ops_at(lv, lv.o_inv_q_Bsk);
-        g.c1 = times_t ? ops_at(lv, lv.o_t_Bsk) : nullptr;
-        g.map = lv.map_Bsk;
-        g.n_limbs = lv.Bsk;
-        g.log_n = ctx->log_n;
-        g.in_stride = in_B_stride;
-        g.out_stride = out_stride;
-        g.total = (polys * lv.Bsk) << ctx->log_n;
-        if (g.total == 0)
-            return CAT_OK;
-        hipLaunchKernelGGL(floor_finish_kernel, dim3(blocks_for(g.total)), dim3(256), 0, s, g);
-        CAT_HIP(hipGetLastError());
-        return CAT_OK;
+        return conv_q_to_Bsk(ctx, lv, in_q, in_q_stride, out, out_stride, times_t ? ops_at(lv, lv.o_t_q) : nullptr, false,
+                             polys, s, 2, in_B, in_B_stride, times_t);
     }
 
-    // in [polys][Bsk][N] -> out [polys][L][N] (out_stride words apart); conv: scratch [polys][L+1][N]
-    cat_status run_fastbconv_sk(cat_ctx *ctx, const BfvLevel &lv, const u64 *in, u64 in_stride, u64 *conv, u64 *out,
-                                u64 out_stride, u64 polys, hipStream_t s)
+    // in [polys][Bsk][N] -> out [polys][L][N] (out_stride words apart): FastBConv_{B -> q} and FastBConv_{B -> m_sk} of
+    // the same staged residues, alpha, and the correction, per coefficient in one thread
+    cat_status run_fastbconv_sk(cat_ctx *ctx, const BfvLevel &lv, const u64 *in, u64 in_stride, u64 *out, u64 out_stride,
+                                u64 polys, hipStream_t s)
     {
-        const u64 N = ctx->n;
         BconvArgs b{};
         b.in = in;
-        b.out = conv;
+        b.out = out;
         b.mods = ctx->d_mods;
         b.inv_punc = ops_at(lv, lv.o_inv_punc_B);
-        b.matrix = lv.d_blob + lv.o_B_to_q;
-        b.imap = lv.map_Bsk; // first |B| entries are base B
+        b.matrix = lv.d_blob + lv.o_B_to_q; // [L + 1][|B|]: the rows of q, then the row of m_sk
+        b.imap = lv.map_Bsk; // first |B| entries are base B; entry |B| is m_sk (the limb alpha needs)
         b.omap = lv.map_q;
-        b.omap.id[lv.L] = (unsigned char)lv.idx_msk;
         b.isz = lv.B;
-        b.osz = lv.L + 1;
+        b.osz = lv.L;
         b.log_n = ctx->log_n;
         b.in_stride = in_stride;
-        b.out_stride = (u64)(lv.L + 1) * N;
+        b.out_stride = out_stride;
         b.total = polys << ctx->log_n;
-        if (b.total == 0)
-            return CAT_OK;
-        hipLaunchKernelGGL(bconv_kernel, dim3(blocks_for(b.total)), dim3(256), b.isz * 256 * sizeof(u64), s, b);
-        CAT_HIP(hipGetLastError());
-        PieceArgs g{};
-        g.in = in;
-        g.out = conv;
-        g.mods = ctx->d_mods;
-        g.c0 = ops_at(lv, lv.o_prodB_q);
-        g.c1 = ops_at(lv, lv.o_negprodB_q);
-        g.map = lv.map_q;
-        g.n_limbs = lv.L;
-        g.log_n = ctx->log_n;
-        g.aux_limb = lv.L;
-        g.in_stride = in_stride;
-        g.out_stride = (u64)(lv.L + 1) * N;
-        g.k1 = lv.inv_B_msk;
-        g.total = (polys * lv.L) << ctx->log_n;
-        hipLaunchKernelGGL(sk_finish_kernel, dim3(blocks_for(g.total)), dim3(256), 0, s, g, out, out_stride, lv.B,
-                           lv.idx_msk);
-        CAT_HIP(hipGetLastError());
-        return CAT_OK;
+        b.ep_c0 = ops_at(lv, lv.o_prodB_q);
+        b.ep_c1 = ops_at(lv, lv.o_negprodB_q);
+        b.ep_k1 = lv.inv_B_msk;
+        b.ep_msk_id = lv.idx_msk;
+        return launch_bconv(b, 3, s);
     }
 } // namespace
 
@@ -653,11 +676,8 @@ cat_status cat_fastbconv_sk(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out,
         return fail(CAT_ERR_INVALID_ARG, "input");
     if (((uintptr_t)d_in | (uintptr_t)d_out) & 15)
         return fail(CAT_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
-    u64 *conv = (u64 *)workspace(ctx, ws_words_fastbconv_sk(ctx->n, L, n_polys) * sizeof(u64));
-    if (!conv)
-        return workspace_status(ctx);
-    return run_fastbconv_sk(ctx, *lv, (const u64 *)d_in, (u64)lv->Bsk * ctx->n, conv, (u64 *)d_out, (u64)L * ctx->n,
-                            n_polys, (hipStream_t)s);
+    return run_fastbconv_sk(ctx, *lv, (const u64 *)d_in, (u64)lv->Bsk * ctx->n, (u64 *)d_out, (u64)L * ctx->n, n_polys,
+                            (hipStream_t)s);
 }
 
 cat_status cat_bfv_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, uint64_t *d_out, uint32_t L,
@@ -680,24 +700,21 @@ cat_status cat_bfv_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d
     hipStream_t s = (hipStream_t)stream;
     const u64 N = ctx->n, Bsk = lv.Bsk, b = batch;
     const u64 pq = (u64)L * N, pB = Bsk * N;
-    // workspace (words): inq [b][4][L][N] | inB [b][4][Bsk][N] | lift [b][4][Bsk+1][N] (reused as conv) |
-    //                    tq [b][3][L][N] | tB [b][3][Bsk][N] | fl [b][3][Bsk][N]
-    const size_t w_inq = b * 4 * pq, w_inB = b * 4 * pB, w_lift = b * 4 * (Bsk + 1) * N, w_tq = b * 3 * pq,
-                 w_tB = b * 3 * pB, w_fl = b * 3 * pB;
-    if (w_inq + w_inB + w_lift + w_tq + w_tB + w_fl != ws_words_bfv_multiply(N, L, Bsk, b))
+    // workspace (words): inq [b][4][L][N] | inB [b][4][Bsk][N] | tq [b][3][L][N] | tB [b][3][Bsk][N] | fl [b][3][Bsk][N]
+    const size_t w_inq = b * 4 * pq, w_inB = b * 4 * pB, w_tq = b * 3 * pq, w_tB = b * 3 * pB, w_fl = b * 3 * pB;
+    if (w_inq + w_inB + w_tq + w_tB + w_fl != ws_words_bfv_multiply(N, L, Bsk, b))
         return fail(CAT_ERR_LOGIC, "workspace formula out of step");
     u64 *ws = (u64 *)workspace(ctx, ws_words_bfv_multiply(N, L, Bsk, b) * sizeof(u64));
     if (!ws)
         return workspace_status(ctx);
-    u64 *inq = ws, *inB = inq + w_inq, *lift = inB + w_inB, *tq = lift + w_lift, *tB = tq + w_tq, *fl = tB + w_tB;
+    u64 *inq = ws, *inB = inq + w_inq, *tq = inB + w_inB, *tB = tq + w_tq, *fl = tB + w_tB;
     // steps (1)-(3), evaluator.cpp:452-490: per input polynomial, lazy NTT in q; lift to Bsk, lazy NTT in Bsk
     CAT_HIP(hipMemcpy2DAsync(inq, 4 * pq * sizeof(u64), d_x, 2 * pq * sizeof(u64), 2 * pq * sizeof(u64), batch,
                              hipMemcpyDeviceToDevice, s));
     CAT_HIP(hipMemcpy2DAsync(inq + 2 * pq, 4 * pq * sizeof(u64), d_y, 2 * pq * sizeof(u64), 2 * pq * sizeof(u64), batch,
                              hipMemcpyDeviceToDevice, s));
-    if ((st = conv_q_to_Bsk(ctx, lv, inq, pq, lift, (Bsk + 1) * N, ops_at(lv, lv.o_mtilde_q), true, b * 4, s)) != CAT_OK)
-        return st;
-    if ((st = run_sm_mrq(ctx, lv, lift, (Bsk + 1) * N, inB, pB, b * 4, s)) != CAT_OK)
+    // fastbconv_m_tilde + sm_mrq as one pass over the coefficients (the lifted [Bsk + 1] residues are never stored)
+    if ((st = conv_q_to_Bsk(ctx, lv, inq, pq, inB, pB, ops_at(lv, lv.o_mtilde_q), false, b * 4, s, 1)) != CAT_OK)
         return st;
     if ((st = launch_ntt(ctx, true, inq, lv.map_q, L, batch * 4, true, s)) != CAT_OK)
         return st;
@@ -734,7 +751,7 @@ cat_status cat_bfv_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d
     // steps (6)-(8), :549-566: multiply by t, fast_floor, fastbconv_sk
     if ((st = run_fast_floor(ctx, lv, tq, pq, tB, pB, fl, pB, true, b * 3, s)) != CAT_OK)
         return st;
-    return run_fastbconv_sk(ctx, lv, fl, pB, lift, (u64 *)d_out, pq, b * 3, s);
+    return run_fastbconv_sk(ctx, lv, fl, pB, (u64 *)d_out, pq, b * 3, s);
 }
 
 } // extern "C"

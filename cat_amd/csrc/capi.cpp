@@ -450,10 +450,7 @@ size_t cat_ctx_workspace_need(const cat_ctx *ctx, uint32_t batch)
     if (ctx->scheme == CAT_SCHEME_BFV)
         for (size_t l = 1; l < ctx->bfv.size(); ++l)
             if (ctx->bfv[l].ready)
-            {
                 take(ws_words_bfv_multiply(N, l, ctx->bfv[l].Bsk, b));
-                take(ws_words_fastbconv_sk(N, l, b * 3));
-            }
     return words * sizeof(u64);
 }
 

@@ -121,11 +121,10 @@ namespace cat
         return polys * N + 2 * polys * (L - 1) * N; // last | tmp | stage (aliased output)
     }
     inline size_t ws_words_mod_drop(size_t N, size_t L, size_t polys) { return polys * (L - 1) * N; }
-    inline size_t ws_words_fastbconv_sk(size_t N, size_t L, size_t polys) { return polys * (L + 1) * N; }
     inline size_t ws_words_bfv_multiply(size_t N, size_t L, size_t Bsk, size_t batch)
     {
-        // inq [b][4][L] | inB [b][4][Bsk] | lift [b][4][Bsk+1] | tq [b][3][L] | tB [b][3][Bsk] | fl [b][3][Bsk]
-        return batch * (4 * L + 4 * Bsk + 4 * (Bsk + 1) + 3 * L + 3 * Bsk + 3 * Bsk) * N;
+        // inq [b][4][L] | inB [b][4][Bsk] | tq [b][3][L] | tB [b][3][Bsk] | fl [b][3][Bsk]
+        return batch * (4 * L + 4 * Bsk + 3 * L + 3 * Bsk + 3 * Bsk) * N;
     }
 
     // Makes the context's device current for the duration of an entry point and restores the caller's device on the
