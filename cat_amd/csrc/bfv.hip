@@ -25,13 +25,17 @@ namespace
         u64 *out;        // [polys][out_limbs_total][N]; the conversion writes limbs out_off..out_off+osz-1
         u64 *mt_out;     // optional: limb index mt_limb of `out` receives the residue modulo 2^32
         const DevMod *mods;
-        const MulOp *premul;  // [isz] or nullptr: x_i <- x_i * premul_i mod q_i first
-        const MulOp *inv_punc; // [isz]
+        const MulOp *inv_punc; // [isz]: (base/b_i)^-1 mod b_i, times the caller's constant when there is one
         const u64 *matrix;    // [osz][isz]
         const u64 *mt_matrix; // [isz] or nullptr
         LimbMap imap, omap;
         u32 isz, osz, log_n;
         u64 in_stride, out_stride; // words between consecutive polys
+        // output placement of poly p: (p / grp) * out_obj_stride + (p % grp) * out_stride (grp = 1: p * out_obj_stride)
+        u32 grp;
+        u64 out_obj_stride;
+        u64 *copy_out;             // optional: the input limbs as read, same placement rule with the copy strides
+        u64 copy_stride, copy_obj_stride;
         u32 out_off, mt_limb;
         u64 total; // polys * N
         // fused tail (template parameter EP of bconv_kernel); constants are per OUTPUT limb
@@ -63,15 +67,17 @@ namespace
         const u32 c = (u32)(i & ((1u << g.log_n) - 1));
         const u64 p = i >> g.log_n;
         const u64 *src = g.in + p * g.in_stride + c;
+        const u64 obj = p / g.grp, sub = p - obj * g.grp;
+        u64 *cpy = g.copy_out ? g.copy_out + obj * g.copy_obj_stride + sub * g.copy_stride + c : nullptr;
         for (u32 j = 0; j < g.isz; ++j)
         {
             const u64 q = g.mods[g.imap.id[j]].q;
-            u64 x = src[(u64)j << g.log_n];
-            if (g.premul)
-                x = mul_shoup(x, g.premul[j].op, g.premul[j].quo, q);
+            const u64 x = src[(u64)j << g.log_n];
+            if (cpy)
+                cpy[(u64)j << g.log_n] = x;
             stage[j * 256 + threadIdx.x] = mul_shoup(x, g.inv_punc[j].op, g.inv_punc[j].quo, q);
         }
-        u64 *dst = g.out + p * g.out_stride + c;
+        u64 *dst = g.out + obj * g.out_obj_stride + sub * g.out_stride + c;
         u64 mt_r = 0, alpha = 0;
         bool alpha_neg = false;
         if (EP == 1)
@@ -358,14 +364,17 @@ namespace cat
             ops.push_back(mk(hm(i), inv));
         }
         lv.o_inv_punc_q = put_ops(ops);
-        ops.clear();
-        for (uint32_t i = 0; i < L; ++i)
-            ops.push_back(mk(hm(i), MT));
-        lv.o_mtilde_q = put_ops(ops);
-        ops.clear();
-        for (uint32_t i = 0; i < L; ++i)
-            ops.push_back(mk(hm(i), ctx->plain_modulus));
-        lv.o_t_q = put_ops(ops);
+        // fastbconv_m_tilde multiplies by m_tilde and fast_floor's caller by t before the conversion scales by
+        // (q/q_i)^-1 (rns.cpp:1104-1113, evaluator.cpp:549-556): x a mod q then b mod q is x (a b mod q) mod q, one multiply
+        const std::vector<MulOp> inv_punc = ops;
+        auto merged = [&](u64 c) {
+            std::vector<MulOp> v;
+            for (uint32_t i = 0; i < L; ++i)
+                v.push_back(mk(hm(i), (u64)((unsigned __int128)(c % q[i]) * inv_punc[i].op % q[i])));
+            return v;
+        };
+        lv.o_mtilde_q = put_ops(merged(MT));
+        lv.o_t_q = put_ops(merged(ctx->plain_modulus));
         ops.clear();
         for (uint32_t i = 0; i < L; ++i)
             ops.push_back(mk(hm(i), mp_mod(prod_B, q[i])));
@@ -501,16 +510,27 @@ namespace
     //   ep 0: plain (+ the residue modulo m_tilde in limb Bsk when with_mt: fastbconv_m_tilde)
     //   ep 1: fastbconv_m_tilde followed by sm_mrq, out [polys][Bsk][N] (evaluator.cpp:466-474 as one pass)
     //   ep 2: fast_floor (rns.cpp:1043-1090): in_B = the Bsk part of the input; times_t multiplies both parts by t first
+    // scale: the input is multiplied by 1 (PRE_NONE), m_tilde (PRE_MT) or t (PRE_T) first
+    enum { PRE_NONE, PRE_MT, PRE_T };
     cat_status conv_q_to_Bsk(cat_ctx *ctx, const BfvLevel &lv, const u64 *in, u64 in_stride, u64 *out, u64 out_stride,
-                             const MulOp *premul, bool with_mt, u64 polys, hipStream_t s, int ep = 0,
-                             const u64 *in_B = nullptr, u64 in_B_stride = 0, bool times_t = false)
+                             int scale, bool with_mt, u64 polys, hipStream_t s, int ep = 0, const u64 *in_B = nullptr,
+                             u64 in_B_stride = 0, const BconvArgs *place = nullptr)
     {
         BconvArgs g{};
         g.in = in;
         g.out = out;
         g.mods = ctx->d_mods;
-        g.premul = premul;
-        g.inv_punc = ops_at(lv, lv.o_inv_punc_q);
+        g.inv_punc = ops_at(lv, scale == PRE_MT ? lv.o_mtilde_q : scale == PRE_T ? lv.o_t_q : lv.o_inv_punc_q);
+        g.grp = 1;
+        g.out_obj_stride = out_stride;
+        if (place) // output grouping and the copy of the input (BFV multiply)
+        {
+            g.grp = place->grp;
+            g.out_obj_stride = place->out_obj_stride;
+            g.copy_out = place->copy_out;
+            g.copy_stride = place->copy_stride;
+            g.copy_obj_stride = place->copy_obj_stride;
+        }
         g.matrix = lv.d_blob + lv.o_q_to_Bsk;
         g.mt_matrix = with_mt || ep == 1 ? lv.d_blob + lv.o_q_to_mt : nullptr;
         g.imap = lv.map_q;
@@ -532,7 +552,7 @@ namespace
         else if (ep == 2)
         {
             g.ep_c0 = ops_at(lv, lv.o_inv_q_Bsk);
-            g.ep_c1 = times_t ? ops_at(lv, lv.o_t_Bsk) : nullptr;
+            g.ep_c1 = scale == PRE_T ? ops_at(lv, lv.o_t_Bsk) : nullptr;
             g.ep_in = in_B;
             g.ep_in_stride = in_B_stride;
         }
@@ -566,8 +586,8 @@ namespace
     cat_status run_fast_floor(cat_ctx *ctx, const BfvLevel &lv, const u64 *in_q, u64 in_q_stride, const u64 *in_B,
                               u64 in_B_stride, u64 *out, u64 out_stride, bool times_t, u64 polys, hipStream_t s)
     {
-        return conv_q_to_Bsk(ctx, lv, in_q, in_q_stride, out, out_stride, times_t ? ops_at(lv, lv.o_t_q) : nullptr, false,
-                             polys, s, 2, in_B, in_B_stride, times_t);
+        return conv_q_to_Bsk(ctx, lv, in_q, in_q_stride, out, out_stride, times_t ? PRE_T : PRE_NONE, false, polys, s, 2, in_B,
+                             in_B_stride);
     }
 
     // in [polys][Bsk][N] -> out [polys][L][N] (out_stride words apart): FastBConv_{B -> q} and FastBConv_{B -> m_sk} of
@@ -588,6 +608,8 @@ namespace
         b.log_n = ctx->log_n;
         b.in_stride = in_stride;
         b.out_stride = out_stride;
+        b.grp = 1;
+        b.out_obj_stride = out_stride;
         b.total = polys << ctx->log_n;
         b.ep_c0 = ops_at(lv, lv.o_prodB_q);
         b.ep_c1 = ops_at(lv, lv.o_negprodB_q);
@@ -629,7 +651,7 @@ cat_status cat_fastbconv_m_tilde(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d
     if (((uintptr_t)d_in | (uintptr_t)d_out) & 15)
         return fail(CAT_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     return conv_q_to_Bsk(ctx, *lv, (const u64 *)d_in, (u64)L * ctx->n, (u64 *)d_out, (u64)(lv->Bsk + 1) * ctx->n,
-                         ops_at(*lv, lv->o_mtilde_q), true, n_polys, (hipStream_t)s);
+                         PRE_MT, true, n_polys, (hipStream_t)s);
 }
 
 cat_status cat_sm_mrq(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys, cat_stream s)
@@ -708,14 +730,21 @@ cat_status cat_bfv_multiply(cat_ctx *ctx, const uint64_t *d_x, const uint64_t *d
     if (!ws)
         return workspace_status(ctx);
     u64 *inq = ws, *inB = inq + w_inq, *tq = inB + w_inB, *tB = tq + w_tq, *fl = tB + w_tB;
-    // steps (1)-(3), evaluator.cpp:452-490: per input polynomial, lazy NTT in q; lift to Bsk, lazy NTT in Bsk
-    CAT_HIP(hipMemcpy2DAsync(inq, 4 * pq * sizeof(u64), d_x, 2 * pq * sizeof(u64), 2 * pq * sizeof(u64), batch,
-                             hipMemcpyDeviceToDevice, s));
-    CAT_HIP(hipMemcpy2DAsync(inq + 2 * pq, 4 * pq * sizeof(u64), d_y, 2 * pq * sizeof(u64), 2 * pq * sizeof(u64), batch,
-                             hipMemcpyDeviceToDevice, s));
-    // fastbconv_m_tilde + sm_mrq as one pass over the coefficients (the lifted [Bsk + 1] residues are never stored)
-    if ((st = conv_q_to_Bsk(ctx, lv, inq, pq, inB, pB, ops_at(lv, lv.o_mtilde_q), false, b * 4, s, 1)) != CAT_OK)
-        return st;
+    // steps (1)-(3), evaluator.cpp:452-490: per input polynomial, lazy NTT in q; lift to Bsk, lazy NTT in Bsk.
+    // fastbconv_m_tilde + sm_mrq run as one pass over the coefficients of x, then of y, where they lie (the lifted
+    // [Bsk + 1] residues are never stored); the same pass leaves the copy of the q limbs that is transformed in place.
+    for (int half = 0; half < 2; ++half)
+    {
+        BconvArgs place{};
+        place.grp = 2;
+        place.out_obj_stride = 4 * pB;
+        place.copy_out = inq + half * 2 * pq;
+        place.copy_stride = pq;
+        place.copy_obj_stride = 4 * pq;
+        if ((st = conv_q_to_Bsk(ctx, lv, (const u64 *)(half ? d_y : d_x), pq, inB + half * 2 * pB, pB, PRE_MT, false, b * 2, s, 1,
+                                nullptr, 0, &place)) != CAT_OK)
+            return st;
+    }
     if ((st = launch_ntt(ctx, true, inq, lv.map_q, L, batch * 4, true, s)) != CAT_OK)
         return st;
     if ((st = launch_ntt(ctx, true, inB, lv.map_Bsk, (uint32_t)Bsk, batch * 4, true, s)) != CAT_OK)

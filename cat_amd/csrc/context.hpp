@@ -23,7 +23,7 @@ namespace cat
         u64 *d_blob = nullptr;
         // offsets into d_blob (in words)
         size_t o_inv_punc_q = 0;   // [L] MulOp: (q/q_i)^-1 mod q_i
-        size_t o_mtilde_q = 0;     // [L] MulOp: m_tilde mod q_i
+        size_t o_mtilde_q = 0;     // [L] MulOp: m_tilde * (q/q_i)^-1 mod q_i (the two reference multiplications as one constant)
         size_t o_q_to_Bsk = 0;     // [Bsk][L]: (q/q_i) mod Bsk_o
         size_t o_q_to_mt = 0;      // [L]: (q/q_i) mod m_tilde
         size_t o_inv_punc_B = 0;   // [B] MulOp: (B/b_i)^-1 mod b_i
@@ -34,7 +34,7 @@ namespace cat
         size_t o_inv_q_Bsk = 0;    // [Bsk] MulOp: q^-1 mod Bsk_i
         size_t o_prodB_q = 0;      // [L] MulOp: B mod q_i
         size_t o_negprodB_q = 0;   // [L] MulOp: -B mod q_i
-        size_t o_t_q = 0;          // [L] MulOp: t mod q_i
+        size_t o_t_q = 0;          // [L] MulOp: t * (q/q_i)^-1 mod q_i
         size_t o_t_Bsk = 0;        // [Bsk] MulOp: t mod Bsk_i
         u64 neg_inv_q_mt = 0;      // -q^-1 mod m_tilde
         MulOp inv_B_msk{};         // B^-1 mod m_sk

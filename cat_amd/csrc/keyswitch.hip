@@ -361,6 +361,9 @@ namespace
     }
 
     // enc[b][comp][j] += (prod[b][comp][j] + qi_lazy - tmp[b][comp][j]) * P^-1 mod q_j   :2810-2816
+    // INLINE (BFV: the correction needs no transform of its own, :2791-2808 is skipped in coefficient form): tmp is formed
+    // here from the special-prime limb as ks_down_prepare_kernel would have written it, no tmp buffer, one kernel less
+    template <bool INLINE>
     __global__ __launch_bounds__(256) void ks_down_finish_kernel(DownArgs g)
     {
         const u64 stride = (u64)gridDim.x * blockDim.x;
@@ -374,7 +377,24 @@ namespace
             const u64 q = g.mods[j].q;
             const MulOp pinv = g.inv_mod[(g.k - 1) * g.k + j];
             const u64 qi_lazy = q << g.lazy_shift;
-            const ulonglong2 t = reinterpret_cast<const ulonglong2 *>(g.tmp)[i];
+            ulonglong2 t;
+            if (INLINE)
+            {
+                const DevMod P = g.mods[g.k - 1], m = g.mods[j];
+                const u64 half = P.q >> 1, fix = q - g.half_mod[(g.k - 1) * g.k + j];
+                t = reinterpret_cast<const ulonglong2 *>(g.prod)[((bc * (g.d + 1) + g.d) << (g.log_n - 1)) + c];
+                t.x = barrett64(t.x + half, P.q, P.ratio1);
+                t.y = barrett64(t.y + half, P.q, P.ratio1);
+                if (P.q > q)
+                {
+                    t.x = barrett64(t.x, q, m.ratio1);
+                    t.y = barrett64(t.y, q, m.ratio1);
+                }
+                t.x += fix;
+                t.y += fix;
+            }
+            else
+                t = reinterpret_cast<const ulonglong2 *>(g.tmp)[i];
             const ulonglong2 p =
                 reinterpret_cast<const ulonglong2 *>(g.prod)[((bc * (g.d + 1) + j) << (g.log_n - 1)) + c];
             ulonglong2 *ep = reinterpret_cast<ulonglong2 *>(g.enc) + (bc >> 1) * g.enc_stride2 +
@@ -682,7 +702,7 @@ namespace cat
         // the BGV branch transforms back fully (:2724), the others lazily (:2763)
         // (with rescale_out the special limb is transformed together with the last limb, below)
         cat_status st = CAT_OK;
-        if (!rescale_out)
+        if (!rescale_out && ckks) // (BFV transforms all d + 1 limbs back in one launch, below)
             st = launch_ntt_ex(ctx, false, prod + (size_t)d * N, mp, 1, batch * 2, !bgv, (u64)rns * N, 1, false, s);
         if (st != CAT_OK)
             return st;
@@ -724,7 +744,7 @@ namespace cat
             st = launch_ntt(ctx, true, tmp, ident, d, batch * 2, true, s);
             if (st != CAT_OK)
                 return st;
-            hipLaunchKernelGGL(ks_down_finish_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+            hipLaunchKernelGGL(ks_down_finish_kernel<false>, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
             CAT_HIP(hipGetLastError());
             return CAT_OK;
         }
@@ -822,15 +842,26 @@ namespace cat
             f.ep_qidx = k - 1;
             return launch_ntt_ex(ctx, true, tmp, ident, d, batch * 2, true, (u64)d * N, 1, false, s, false, &f);
         }
+        if (!ckks)
+        {
+            // BFV: the whole product, special limb included, goes back to coefficient form (lazy, :2763) in one launch and
+            // the correction is applied there
+            LimbMap ext{};
+            for (u32 I = 0; I < rns; ++I)
+                ext.id[I] = (unsigned char)(I == d ? k - 1 : I);
+            st = launch_ntt_ex(ctx, false, prod, ext, rns, batch * 2, true, (u64)rns * N, 1, false, s);
+            if (st != CAT_OK)
+                return st;
+            hipLaunchKernelGGL(ks_down_finish_kernel<true>, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+            CAT_HIP(hipGetLastError());
+            return CAT_OK;
+        }
         hipLaunchKernelGGL(ks_down_prepare_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
         CAT_HIP(hipGetLastError());
-        if (ckks)
-            st = launch_ntt(ctx, true, tmp, ident, d, batch * 2, true, s);
-        else
-            st = launch_ntt_ex(ctx, false, prod, ident, d, batch * 2, true, (u64)rns * N, 1, false, s);
+        st = launch_ntt(ctx, true, tmp, ident, d, batch * 2, true, s);
         if (st != CAT_OK)
             return st;
-        hipLaunchKernelGGL(ks_down_finish_kernel, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(ks_down_finish_kernel<false>, dim3(grid_for(g.total2)), dim3(256), 0, s, g);
         CAT_HIP(hipGetLastError());
 
         return CAT_OK;
