@@ -23,7 +23,6 @@ namespace
     {
         const u64 *in;   // [polys][in_limbs_total][N]; the conversion reads limbs 0..isz-1
         u64 *out;        // [polys][out_limbs_total][N]; the conversion writes limbs out_off..out_off+osz-1
-        u64 *mt_out;     // optional: limb index mt_limb of `out` receives the residue modulo 2^32
         const DevMod *mods;
         const MulOp *inv_punc; // [isz]: (base/b_i)^-1 mod b_i, times the caller's constant when there is one
         const u64 *matrix;    // [osz][isz]
@@ -57,11 +56,34 @@ namespace
     //   3  fastbconv_sk tail (rns.cpp:930-977): alpha = (v_sk + (m_sk - in_sk)) * B^-1 mod m_sk, centred;
     //        out_i = v_i + (alpha > m_sk/2 ? (m_sk - alpha) * (B mod q_i) : alpha * (-B mod q_i))      ep_c0 = B, ep_c1 = -B
     // Same values as the separate kernels (cat_sm_mrq keeps the standalone form); one write instead of write + read + write.
-    template <int EP>
+    // W: coefficients per thread (1 or 2).  Two make every global access 16 bytes per lane and every matrix word (a scalar
+    // load) serve two dot products; the staged residues then take isz x 4 KB of LDS, so the launcher uses W = 2 up to 16
+    // input limbs.
+    template <int W>
+    __device__ __forceinline__ void ldw(u64 (&v)[W], const u64 *p)
+    {
+        if constexpr (W == 2)
+        {
+            const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(p);
+            v[0] = t.x, v[1] = t.y;
+        }
+        else
+            v[0] = *p;
+    }
+    template <int W>
+    __device__ __forceinline__ void stw(u64 *p, const u64 (&v)[W])
+    {
+        if constexpr (W == 2)
+            *reinterpret_cast<ulonglong2 *>(p) = make_ulonglong2(v[0], v[1]);
+        else
+            *p = v[0];
+    }
+
+    template <int EP, int W>
     __global__ __launch_bounds__(256) void bconv_kernel(BconvArgs g)
     {
-        extern __shared__ u64 stage[]; // [isz][256]
-        const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+        extern __shared__ __align__(16) u64 stage[]; // [isz][256][W]
+        const u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) * W;
         if (i >= g.total)
             return;
         const u32 c = (u32)(i & ((1u << g.log_n) - 1));
@@ -69,74 +91,131 @@ namespace
         const u64 *src = g.in + p * g.in_stride + c;
         const u64 obj = p / g.grp, sub = p - obj * g.grp;
         u64 *cpy = g.copy_out ? g.copy_out + obj * g.copy_obj_stride + sub * g.copy_stride + c : nullptr;
+        u64 *mine = stage + (size_t)threadIdx.x * W; // + j * 256 * W
         for (u32 j = 0; j < g.isz; ++j)
         {
             const u64 q = g.mods[g.imap.id[j]].q;
-            const u64 x = src[(u64)j << g.log_n];
+            u64 x[W];
+            ldw<W>(x, src + ((u64)j << g.log_n));
             if (cpy)
-                cpy[(u64)j << g.log_n] = x;
-            stage[j * 256 + threadIdx.x] = mul_shoup(x, g.inv_punc[j].op, g.inv_punc[j].quo, q);
+                stw<W>(cpy + ((u64)j << g.log_n), x);
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                x[w] = mul_shoup(x[w], g.inv_punc[j].op, g.inv_punc[j].quo, q);
+            stw<W>(mine + j * 256 * W, x);
         }
         u64 *dst = g.out + obj * g.out_obj_stride + sub * g.out_stride + c;
-        u64 mt_r = 0, alpha = 0;
-        bool alpha_neg = false;
+        // one dot product of the staged residues with a matrix row, both coefficients
+        auto dot = [&](const u64 *row, const DevMod &m, u64 (&v)[W]) {
+            Acc acc[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                acc[w].lo = acc[w].hi = 0, acc[w].cc = 0;
+            u32 j = 0;
+            // scaled residues and matrix entries are canonical modulo primes of at most 61 bits: rm_mac's bounds
+            for (; j + 2 <= g.isz; j += 2)
+            {
+                u64 x0[W], x1[W];
+                ldw<W>(x0, mine + j * 256 * W);
+                ldw<W>(x1, mine + (j + 1) * 256 * W);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    u64 mid;
+                    rm_mac2(acc[w], mid, x0[w], row[j], x1[w], row[j + 1]);
+                    rm_fold(acc[w], mid);
+                }
+            }
+            if (j < g.isz)
+            {
+                u64 x0[W];
+                ldw<W>(x0, mine + j * 256 * W);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    u64 mid = 0;
+                    rm_mac(acc[w], mid, x0[w], row[j]);
+                    rm_fold(acc[w], mid);
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                v[w] = barrett128(acc[w].lo, acc[w].hi + acc[w].cc, m.q, m.ratio0, m.ratio1);
+        };
+        u64 mt_r[W], alpha[W];
+        bool alpha_neg[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+            mt_r[w] = alpha[w] = 0, alpha_neg[w] = false;
         if (EP == 1)
         {
-            u64 acc = 0;
+            u64 acc[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                acc[w] = 0;
             for (u32 j = 0; j < g.isz; ++j)
-                acc += stage[j * 256 + threadIdx.x] * g.mt_matrix[j];
-            mt_r = ((acc & (MT - 1)) * g.ep_k0) & (MT - 1);
+            {
+                u64 x[W];
+                ldw<W>(x, mine + j * 256 * W);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    acc[w] += x[w] * g.mt_matrix[j];
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                mt_r[w] = ((acc[w] & (MT - 1)) * g.ep_k0) & (MT - 1);
         }
         if (EP == 3)
         {
             const DevMod m = g.mods[g.ep_msk_id];
-            const u64 *row = g.matrix + (u64)g.osz * g.isz;
-            Acc acc;
-            acc.lo = acc.hi = 0;
-            acc.cc = 0;
-            u32 j = 0;
-            for (; j + 2 <= g.isz; j += 2)
+            u64 conv_sk[W], in_sk[W];
+            dot(g.matrix + (u64)g.osz * g.isz, m, conv_sk);
+            ldw<W>(in_sk, src + ((u64)g.isz << g.log_n));
+#pragma unroll
+            for (int w = 0; w < W; ++w)
             {
-                u64 mid;
-                rm_mac2(acc, mid, stage[j * 256 + threadIdx.x], row[j], stage[(j + 1) * 256 + threadIdx.x], row[j + 1]);
-                rm_fold(acc, mid);
+                alpha[w] = mul_shoup(conv_sk[w] + (m.q - in_sk[w]), g.ep_k1.op, g.ep_k1.quo, m.q);
+                alpha_neg[w] = alpha[w] > (m.q >> 1);
+                if (alpha_neg[w])
+                    alpha[w] = m.q - alpha[w];
             }
-            if (j < g.isz)
-            {
-                u64 mid = 0;
-                rm_mac(acc, mid, stage[j * 256 + threadIdx.x], row[j]);
-                rm_fold(acc, mid);
-            }
-            const u64 conv_sk = barrett128(acc.lo, acc.hi + acc.cc, m.q, m.ratio0, m.ratio1);
-            const u64 in_sk = src[(u64)g.isz << g.log_n];
-            alpha = mul_shoup(conv_sk + (m.q - in_sk), g.ep_k1.op, g.ep_k1.quo, m.q);
-            alpha_neg = alpha > (m.q >> 1);
-            if (alpha_neg)
-                alpha = m.q - alpha;
         }
-        // v: canonical residue modulo output prime o
-        auto finish = [&](u32 o, u64 v, u64 q) -> u64 {
+        // v: canonical residues modulo output prime o (index within the conversion), finished and stored
+        auto finish_store = [&](u32 o, u64 (&v)[W], u64 q) {
             if (EP == 1)
             {
-                u64 t = mt_r;
-                if (t >= (MT >> 1))
-                    t += q - MT;
-                const u64 a = mul_shoup(t, g.ep_c0[o].op, g.ep_c0[o].quo, q);
-                return mul_shoup(add_mod(a, v, q), g.ep_c1[o].op, g.ep_c1[o].quo, q);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    u64 t = mt_r[w];
+                    if (t >= (MT >> 1))
+                        t += q - MT;
+                    const u64 a = mul_shoup(t, g.ep_c0[o].op, g.ep_c0[o].quo, q);
+                    v[w] = mul_shoup(add_mod(a, v[w], q), g.ep_c1[o].op, g.ep_c1[o].quo, q);
+                }
             }
             if (EP == 2)
             {
-                u64 x = g.ep_in[p * g.ep_in_stride + ((u64)o << g.log_n) + c];
-                if (g.ep_c1)
-                    x = mul_shoup(x, g.ep_c1[o].op, g.ep_c1[o].quo, q);
-                return mul_shoup(x + (q - v), g.ep_c0[o].op, g.ep_c0[o].quo, q);
+                u64 x[W];
+                ldw<W>(x, g.ep_in + p * g.ep_in_stride + ((u64)o << g.log_n) + c);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    if (g.ep_c1)
+                        x[w] = mul_shoup(x[w], g.ep_c1[o].op, g.ep_c1[o].quo, q);
+                    v[w] = mul_shoup(x[w] + (q - v[w]), g.ep_c0[o].op, g.ep_c0[o].quo, q);
+                }
             }
             if (EP == 3)
             {
-                const MulOp w = alpha_neg ? g.ep_c0[o] : g.ep_c1[o];
-                return add_mod(mul_shoup(alpha, w.op, w.quo, q), v, q);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    const MulOp k = alpha_neg[w] ? g.ep_c0[o] : g.ep_c1[o];
+                    v[w] = add_mod(mul_shoup(alpha[w], k.op, k.quo, q), v[w], q);
+                }
             }
-            return v;
+            stw<W>(dst + ((u64)(g.out_off + o) << g.log_n), v);
         };
         u32 o = 0;
         // four output residues at a time: one read of the staged residues serves four dot products, and their folds go
@@ -144,69 +223,85 @@ namespace
         for (; o + 4 <= g.osz; o += 4)
         {
             const u64 *row = g.matrix + (u64)o * g.isz;
-            Acc acc[4];
+            Acc acc[W][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                acc[k].lo = acc[k].hi = 0, acc[k].cc = 0;
+            for (int w = 0; w < W; ++w)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    acc[w][k].lo = acc[w][k].hi = 0, acc[w][k].cc = 0;
             u32 j = 0;
             for (; j + 2 <= g.isz; j += 2)
             {
-                const u64 x0 = stage[j * 256 + threadIdx.x], x1 = stage[(j + 1) * 256 + threadIdx.x];
-                u64 mid[4];
+                u64 x0[W], x1[W];
+                ldw<W>(x0, mine + j * 256 * W);
+                ldw<W>(x1, mine + (j + 1) * 256 * W);
+                u64 m0[4], m1[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    rm_mac2(acc[k], mid[k], x0, row[k * g.isz + j], x1, row[k * g.isz + j + 1]);
-                rm_fold4(acc[0], acc[1], acc[2], acc[3], mid[0], mid[1], mid[2], mid[3]);
+                    m0[k] = row[k * g.isz + j], m1[k] = row[k * g.isz + j + 1];
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    u64 mid[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        rm_mac2(acc[w][k], mid[k], x0[w], m0[k], x1[w], m1[k]);
+                    rm_fold4(acc[w][0], acc[w][1], acc[w][2], acc[w][3], mid[0], mid[1], mid[2], mid[3]);
+                }
             }
             if (j < g.isz)
             {
-                const u64 x0 = stage[j * 256 + threadIdx.x];
-                u64 mid[4];
+                u64 x0[W];
+                ldw<W>(x0, mine + j * 256 * W);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int w = 0; w < W; ++w)
                 {
-                    mid[k] = 0;
-                    rm_mac(acc[k], mid[k], x0, row[k * g.isz + j]);
+                    u64 mid[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        mid[k] = 0;
+                        rm_mac(acc[w][k], mid[k], x0[w], row[k * g.isz + j]);
+                    }
+                    rm_fold4(acc[w][0], acc[w][1], acc[w][2], acc[w][3], mid[0], mid[1], mid[2], mid[3]);
                 }
-                rm_fold4(acc[0], acc[1], acc[2], acc[3], mid[0], mid[1], mid[2], mid[3]);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
             {
                 const DevMod m = g.mods[g.omap.id[o + k]];
-                dst[(u64)(g.out_off + o + k) << g.log_n] =
-                    finish(o + k, barrett128(acc[k].lo, acc[k].hi + acc[k].cc, m.q, m.ratio0, m.ratio1), m.q);
+                u64 v[W];
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    v[w] = barrett128(acc[w][k].lo, acc[w][k].hi + acc[w][k].cc, m.q, m.ratio0, m.ratio1);
+                finish_store(o + k, v, m.q);
             }
         }
         for (; o < g.osz; ++o)
         {
             const DevMod m = g.mods[g.omap.id[o]];
-            const u64 *row = g.matrix + (u64)o * g.isz;
-            // scaled residues and matrix entries are canonical modulo primes of at most 61 bits: rm_mac's bounds
-            Acc acc;
-            acc.lo = acc.hi = 0;
-            acc.cc = 0;
-            u32 j = 0;
-            for (; j + 2 <= g.isz; j += 2)
-            {
-                u64 mid;
-                rm_mac2(acc, mid, stage[j * 256 + threadIdx.x], row[j], stage[(j + 1) * 256 + threadIdx.x], row[j + 1]);
-                rm_fold(acc, mid);
-            }
-            if (j < g.isz)
-            {
-                u64 mid = 0;
-                rm_mac(acc, mid, stage[j * 256 + threadIdx.x], row[j]);
-                rm_fold(acc, mid);
-            }
-            dst[(u64)(g.out_off + o) << g.log_n] = finish(o, barrett128(acc.lo, acc.hi + acc.cc, m.q, m.ratio0, m.ratio1), m.q);
+            u64 v[W];
+            dot(g.matrix + (u64)o * g.isz, m, v);
+            finish_store(o, v, m.q);
         }
         if (EP == 0 && g.mt_matrix)
         {
-            u64 acc = 0;
+            u64 acc[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                acc[w] = 0;
             for (u32 j = 0; j < g.isz; ++j)
-                acc += stage[j * 256 + threadIdx.x] * g.mt_matrix[j];
-            dst[(u64)g.mt_limb << g.log_n] = acc & (MT - 1);
+            {
+                u64 x[W];
+                ldw<W>(x, mine + j * 256 * W);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    acc[w] += x[w] * g.mt_matrix[j];
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                acc[w] &= MT - 1;
+            stw<W>(dst + ((u64)g.mt_limb << g.log_n), acc);
         }
     }
 
@@ -493,14 +588,20 @@ namespace
     {
         if (g.total == 0)
             return CAT_OK;
-        const dim3 grid(blocks_for(g.total)), block(256);
-        const size_t lds = g.isz * 256 * sizeof(u64);
-        switch (ep)
+        // two coefficients per thread while the staged residues fit 64 KB of LDS (isz <= 16)
+        const bool two = g.isz <= 16 && (g.total & 1) == 0;
+        const dim3 grid(blocks_for(two ? g.total / 2 : g.total)), block(256);
+        const size_t lds = g.isz * 256 * sizeof(u64) * (two ? 2 : 1);
+        switch (ep * 2 + (two ? 1 : 0))
         {
-        case 0: hipLaunchKernelGGL(bconv_kernel<0>, grid, block, lds, s, g); break;
-        case 1: hipLaunchKernelGGL(bconv_kernel<1>, grid, block, lds, s, g); break;
-        case 2: hipLaunchKernelGGL(bconv_kernel<2>, grid, block, lds, s, g); break;
-        default: hipLaunchKernelGGL(bconv_kernel<3>, grid, block, lds, s, g); break;
+        case 0: hipLaunchKernelGGL((bconv_kernel<0, 1>), grid, block, lds, s, g); break;
+        case 1: hipLaunchKernelGGL((bconv_kernel<0, 2>), grid, block, lds, s, g); break;
+        case 2: hipLaunchKernelGGL((bconv_kernel<1, 1>), grid, block, lds, s, g); break;
+        case 3: hipLaunchKernelGGL((bconv_kernel<1, 2>), grid, block, lds, s, g); break;
+        case 4: hipLaunchKernelGGL((bconv_kernel<2, 1>), grid, block, lds, s, g); break;
+        case 5: hipLaunchKernelGGL((bconv_kernel<2, 2>), grid, block, lds, s, g); break;
+        case 6: hipLaunchKernelGGL((bconv_kernel<3, 1>), grid, block, lds, s, g); break;
+        default: hipLaunchKernelGGL((bconv_kernel<3, 2>), grid, block, lds, s, g); break;
         }
         CAT_HIP(hipGetLastError());
         return CAT_OK;

@@ -547,10 +547,12 @@ def test_rescale_reference_known_answers(cat, oracle):
 # ------------------------------------------------------------------------------------- BFV / BEHZ
 
 
-@pytest.mark.parametrize("log_n,bits,t", [(3, [30, 30, 31], 17), (12, [36, 36, 37], 65537), (11, [54], 1032193)])
+@pytest.mark.parametrize("log_n,bits,t", [(3, [30, 30, 31], 17), (12, [36, 36, 37], 65537), (11, [54], 1032193),
+                                          (6, [40] * 19, 65537)])
 def test_behz_pieces_match_oracle(cat, oracle, log_n, bits, t):
     """fastbconv_m_tilde / sm_mrq / fast_floor / fastbconv_sk (util/rns.cpp:903-1131) against the oracle's
-    RNSTool (itself pinned by tests/util/rns.cpp:460-853 in test_oracle_known_answers.py)."""
+    RNSTool (itself pinned by tests/util/rns.cpp:460-853 in test_oracle_known_answers.py).  The conversion kernel
+    handles two coefficients per thread up to 16 input limbs and one beyond: the 19-prime case walks over both."""
     n = 1 << log_n
     primes = oracle.coeff_modulus_create(n, bits)
     ctx = cat.Context(log_n, primes, cat.SCHEME_BFV, t)
@@ -581,7 +583,8 @@ def test_behz_pieces_match_oracle(cat, oracle, log_n, bits, t):
     ctx.close()
 
 
-@pytest.mark.parametrize("log_n,bits,t", [(12, [36, 36, 37], 65537), (13, [43, 43, 44, 44, 44], 786433), (10, [27], 12289)])
+@pytest.mark.parametrize("log_n,bits,t", [(12, [36, 36, 37], 65537), (13, [43, 43, 44, 44, 44], 786433), (10, [27], 12289),
+                                          (6, [40] * 19, 65537)])
 def test_bfv_multiply_relinearize_matches_oracle(cat, oracle, log_n, bits, t):
     n = 1 << log_n
     primes = oracle.coeff_modulus_create(n, bits)
