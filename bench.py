@@ -225,6 +225,10 @@ def main():
     # rehearsal of the N > 1 code path on a one-GPU box: every rank on cuda:0, collectives over gloo (RCCL refuses two
     # ranks on one device); the numbers of such a run mean nothing and the line says so
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help=argparse.SUPPRESS)
+    # one process, one-rank communicator: drives the guarded product path below on a one-GPU box (tests/test_gpu_comm.py)
+    ap.add_argument("--rccl-selftest", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rccl-timeout", type=float, default=120.0,
+                    help="seconds the product's RCCL key broadcast may take (N > 1) before torch.distributed takes over")
     args = ap.parse_args()
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus is None:  # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's word counts
@@ -299,19 +303,55 @@ def main():
     # The only collective, outside the timed region: the product's own cat_key_broadcast (C ABI) on an RCCL communicator
     # made here (one rank per GPU over xGMI).  The gloo rehearsal on one GPU keeps torch.distributed's broadcast: RCCL
     # refuses two ranks on one device.
-    comm = None
-    if world > 1 and not args.rehearse_on_one_gpu:
-        comm = sharding.RcclComm(world, rank)
-        dist.barrier()
-    t0 = time.perf_counter()
-    if comm is not None:
-        ctx.key_broadcast(key, comm.handle, root=0)
-        key_bcast_via = "cat_key_broadcast (RCCL communicator of the bench's own)"
+    # Its first run on more than one GPU is the driver's scaling run, so it is guarded: communicator set-up and the
+    # broadcast run in a worker thread with a time limit, the ranks then agree (all_reduce MIN over the process group)
+    # whether every one of them got through, and if not the key goes out through torch.distributed instead -- the
+    # bench line says which way it went and why.
+    key_bcast_s = 0.0
+    comm = None  # the communicator, once it has carried a broadcast on every rank
+    if (world > 1 or args.rccl_selftest) and not args.rehearse_on_one_gpu:
+        import threading
+
+        box = {}
+
+        def product_path():
+            try:
+                torch.cuda.set_device(local_rank)  # the current device is per thread
+                comm = sharding.RcclComm(world, rank)
+                box["comm"] = comm
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.key_broadcast(key, comm.handle, root=0)
+                torch.cuda.synchronize()
+                box["s"] = time.perf_counter() - t0
+            except Exception as e:  # noqa: BLE001 -- reported in the bench line, the fallback takes over
+                box["error"] = f"{type(e).__name__}: {e}"
+
+        worker = threading.Thread(target=product_path, daemon=True)
+        worker.start()
+        worker.join(timeout=args.rccl_timeout)
+        mine_ok = (not worker.is_alive()) and "s" in box
+        flag = torch.tensor([1 if mine_ok else 0], dtype=torch.int32, device=device)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            key_bcast_s = box["s"]
+            comm = box["comm"]
+            key_bcast_via = "cat_key_broadcast (RCCL communicator of the bench's own)"
+        else:
+            why = box.get("error") or ("timed out" if worker.is_alive() else "another rank failed")
+            t0 = time.perf_counter()
+            sharding.broadcast_key(key, src=0)
+            torch.cuda.synchronize()
+            key_bcast_s = time.perf_counter() - t0
+            key_bcast_via = f"torch.distributed broadcast (cat_key_broadcast did not complete on every rank; rank {rank}: {why})"
     else:
+        t0 = time.perf_counter()
         sharding.broadcast_key(key, src=0)
+        torch.cuda.synchronize()
+        key_bcast_s = time.perf_counter() - t0 if world > 1 else 0.0
         key_bcast_via = "torch.distributed broadcast (gloo rehearsal)" if world > 1 else "single process: no collective"
-    torch.cuda.synchronize()
-    key_bcast_s = time.perf_counter() - t0 if world > 1 else 0.0
+    key_bcast_s = sharding.max_over_ranks(key_bcast_s, device) if world > 1 else key_bcast_s
     prod = torch.empty((B, 3, L, N), dtype=torch.int64, device=device)
     out = torch.empty((B, 2, L - 1, N), dtype=torch.int64, device=device)
 
@@ -563,8 +603,9 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.barrier()  # rank 0 may still be in its roofline leg
-        if comm is not None:
-            comm.close()
+    if comm is not None:
+        comm.close()
+    if world > 1:
         dist.destroy_process_group()
 
 

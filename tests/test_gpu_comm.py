@@ -72,3 +72,22 @@ def test_bench_communicator_class_on_one_rank():
     finally:
         comm.close()
     ctx.close()
+
+
+def test_bench_guarded_product_broadcast_runs_on_a_one_rank_communicator():
+    """bench.py's N > 1 key broadcast runs in a worker thread with a time limit and falls back to torch.distributed when
+    it does not complete on every rank.  --rccl-selftest drives that code with one rank (its own device binding, the
+    communicator, cat_key_broadcast from a second thread); the line must say the product's collective carried the key."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--rccl-selftest", "--steps", "2", "--warmup", "1", "--settle", "0",
+                        "--skip-ntt", "--skip-cpu", "--skip-latency", "--batch", "2", "--limbs", "4"],
+                       cwd=root, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["key_broadcast_via"].startswith("cat_key_broadcast"), line["config"]["key_broadcast_via"]
+    assert line["parity_checked"] is True
