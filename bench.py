@@ -310,8 +310,6 @@ def main():
     key_bcast_s = 0.0
     comm = None  # the communicator, once it has carried a broadcast on every rank
     if (world > 1 or args.rccl_selftest) and not args.rehearse_on_one_gpu:
-        import threading
-
         box = {}
 
         def product_path():
