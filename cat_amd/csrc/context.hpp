@@ -158,9 +158,11 @@ namespace cat
     //  - epilogue of the last pass (evaluator.cpp:2810-2816, util/rns.cpp:879-899): the transformed limb t (< 4q) is
     //      not stored; dest = (other + 4q - t) * Q^-1 mod q  [+ dest when ep_acc], with object p = b * ep_S + s
     //      addressed as base + b * *_b + s * *_s + limb * N.
-    // true when every prime the map names (first n_groups entries) is below 2^60: forward transforms then run with
-    // the wide lazy ranges (ntt.hip, policy Wide) and a first-pass-only result holds values < 16q instead of < 8q
-    bool ntt_wide(const cat_ctx *ctx, const LimbMap &map, uint32_t n_groups);
+    // range policy of a forward transform over the primes the map names (first n_groups entries), ntt.hip:
+    //   1  every prime below 2^60: wide lazy ranges (policy Wide), a first-pass-only result holds values < 16q instead of < 8q
+    //   2  every prime of 36 to 57 bits: no guards at all (policy Wider), a first-pass-only result holds values < 36q
+    //   0  otherwise
+    int ntt_wide(const cat_ctx *ctx, const LimbMap &map, uint32_t n_groups);
     struct NttFuse
     {
         const u64 *src = nullptr;

@@ -142,6 +142,7 @@ namespace
 
     // Every prime of a scheme context is below 2^60 (cat_ctx_create), so the rows run with the wide lazy ranges and
     // their results (< 4q < 2^62) meet rm_mac's operand bound as they are.
+    template <int WIDE>
     __global__ __launch_bounds__(256, 2) void ks_rows_mac_kernel(RowsMacArgs g)
     {
         __shared__ __align__(16) u64 lds[RM_TW_WORDS + RM_X_WORDS];
@@ -223,7 +224,7 @@ namespace
             u64 ka[8], kb[8];
             rm_load8(ka, kp0);
             rm_load8(kb, kp1);
-            rm_rows<2, true>(x, tw, xs, t, q, red_r, red_shift);
+            rm_rows<2, WIDE>(x, tw, xs, t, q, red_r, red_shift);
 #pragma unroll
             for (int cidx = 0; cidx < 2; ++cidx)
             {
@@ -255,7 +256,7 @@ namespace
 #pragma unroll
             for (int a = 0; a < 8; ++a)
                 x[0][a] = ebase[(size_t)J0 * N + a * 32];
-            rm_rows<1, true>(x, tw, xs, t, q, red_r, red_shift);
+            rm_rows<1, WIDE>(x, tw, xs, t, q, red_r, red_shift);
             mac(x[0], J0, x[0], J0, false);
         }
         // d < 256: the reference's lazy counter never triggers an intermediate reduction (:2619-2707)
@@ -917,7 +918,7 @@ namespace cat
         // step 2: modulus raise fused into the first NTT pass (ntt.hip Source): ext is written once, already
         // half transformed, instead of being written by a raise kernel and re-read
         const bool fused_mac = log_n >= 12;
-        bool wide = false;
+        int wide = 0;
         {
             LimbMap map{};
             for (u32 I = 0; I < rns; ++I)
@@ -955,7 +956,10 @@ namespace cat
                 return fail(CAT_ERR_LOGIC, "invalid parameters");
             if (!wide)
                 return fail(CAT_ERR_LOGIC, "invalid parameters"); // unreachable: scheme contexts hold primes < 2^60
-            hipLaunchKernelGGL(ks_rows_mac_kernel, dim3((u32)blocks), dim3(256), 0, s, g);
+            if (wide == 2)
+                hipLaunchKernelGGL(ks_rows_mac_kernel<2>, dim3((u32)blocks), dim3(256), 0, s, g);
+            else
+                hipLaunchKernelGGL(ks_rows_mac_kernel<1>, dim3((u32)blocks), dim3(256), 0, s, g);
             CAT_HIP(hipGetLastError());
         }
         else

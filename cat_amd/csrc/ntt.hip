@@ -284,7 +284,7 @@ namespace
     // ---- arithmetic policies ----------------------------------------------------------------------------
     struct Exact
     {
-        static constexpr bool WIDE = false;
+        static constexpr int WIDE = 0;
         static constexpr bool INV_WIDE = false;
         typedef MulOp Tw;
         typedef const MulOp *Table;
@@ -338,7 +338,7 @@ namespace
 
     struct Fast
     {
-        static constexpr bool WIDE = false;
+        static constexpr int WIDE = 0; // 0: guard in every stage, 1: policy Wide, 2: policy Wider
         static constexpr bool INV_WIDE = false;
         typedef MulOp3 Tw;
         struct Table
@@ -431,7 +431,17 @@ namespace
     // contract (< 4q lazy, canonical otherwise) by the final reduction.
     struct Wide : Fast
     {
-        static constexpr bool WIDE = true;
+        static constexpr int WIDE = 1;
+    };
+    // The same with NO guard at all, forward transforms whose primes all have 36 to 57 bits -- every default coefficient
+    // modulus of the reference (CoeffModulus::BFVDefault, util/globals.cpp:25-70: at most 56 bits) and CKKS chains of
+    // such primes.  Sixteen stages add at most 64q to inputs below 4q: 68q < 2^64 for q < 2^57, so the values simply grow
+    // and the last pass brings them down with one estimated-quotient reduction (reduce_below_2q takes any 64-bit
+    // operand when the prime has 36 bits or more): 14 instead of 16 instructions per butterfly.  A first-pass-only
+    // result holds values below 36q.
+    struct Wider : Fast
+    {
+        static constexpr int WIDE = 2;
     };
     // Fast arithmetic with wide lazy ranges for INVERSE transforms whose primes all have 36 to 60 bits.  A Gentleman-
     // Sande butterfly doubles the range of its sum and its product comes out below 4q whatever went in, so with values
@@ -454,12 +464,25 @@ namespace
     template <class P>
     __device__ __forceinline__ constexpr int col_guard(int global_stage)
     {
-        return !P::WIDE ? 1 : ((global_stage & 1) && global_stage >= 3) ? 2 : 0;
+        return P::WIDE == 2 ? 0 : !P::WIDE ? 1 : ((global_stage & 1) && global_stage >= 3) ? 2 : 0;
     }
     template <class P>
     __device__ __forceinline__ constexpr int row_guard(int local_stage)
     {
-        return !P::WIDE ? 1 : (local_stage & 1) ? 0 : 2;
+        return P::WIDE == 2 ? 0 : !P::WIDE ? 1 : (local_stage & 1) ? 0 : 2;
+    }
+
+    // end of a forward transform: from the policy's range to the contract (lazy: below 4q; else canonical)
+    template <class P>
+    __device__ __forceinline__ u64 finish_fwd_any(u64 x, const typename P::Mod &m, bool lazy)
+    {
+        if constexpr (P::WIDE == 2)
+        {
+            x = reduce_below_2q(x, m.red_r, m.red_shift, m.nq);
+            return lazy ? x : guard(x, m.q, m.nq);
+        }
+        else
+            return P::finish_fwd(P::WIDE ? guard(x, m.K << 1, m.negK << 1) : x, m, lazy);
     }
 
     // Column passes, Fast policy: the first log2(N1) <= 8 forward stages use table entries 1 .. N1-1, the last
@@ -593,7 +616,7 @@ namespace
         constexpr int C = TW / N1;             // columns per workgroup (TW / 16 threads)
         constexpr int SUB = 16 >> K1;          // consecutive rows per thread in round 1
         u64 *p = a.data + w.offset + w.tile * C;
-        const Source in = source(a, w, w.tile * C, P::WIDE);
+        const Source in = source(a, w, w.tile * C, P::WIDE != 0);
 
         const u32 c = threadIdx.x % C, tau = threadIdx.x / C;
         u64 x[16];
@@ -692,7 +715,7 @@ namespace
         fwd_stage16<P, 3, row_guard<P>(7)>(x, tw, base2, m);
 #pragma unroll
         for (int l = 0; l < 16; ++l)
-            x[l] = P::finish_fwd(P::WIDE ? guard(x[l], m.K << 1, m.negK << 1) : x[l], m, a.lazy != 0);
+            x[l] = finish_fwd_any<P>(x[l], m, a.lazy != 0);
         wave_lds_sync();
 #pragma unroll
         for (int l = 0; l < 16; ++l)
@@ -755,7 +778,7 @@ namespace
     // ND: polynomials in flight per thread (they share every twiddle read from LDS).  ND = 1 halves the bytes a thread
     // has in flight, which the access-only skeleton likes (profiles/r03_pass_shapes.txt: 5.41 against 4.96 TB/s), but the
     // kernel itself takes 3.5 % longer with it (config 2 forward 14.60 against 14.08 ms, same box): ND = 2 stays
-    template <bool WIDE, int ND = 2>
+    template <int WIDE, int ND = 2>
     __global__ __launch_bounds__(256, 2) void ntt_fwd_rows8(NttArgs a, u32 chunks)
     {
         __shared__ __align__(16) u64 lds[RM_TW_WORDS + RM_X_WORDS];
@@ -768,7 +791,7 @@ namespace
         const u32 mod = a.map.id[grp];
         const u64 q = a.mods[mod].q, nq = 0 - q;
         const u32 red_r = a.mods[mod].red_r, red_shift = a.mods[mod].red_shift;
-        const bool below_2q = WIDE && red_r != 0; // what rm_rows hands back
+        const bool below_2q = WIDE != 0 && red_r != 0; // what rm_rows hands back
         rm_stage_twiddles(lds, reinterpret_cast<const u64 *>(a.tw) + ((size_t)mod * 3 << a.log_n), a.log_n, tile);
         __syncthreads();
         const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1235,8 +1258,8 @@ namespace
             ulonglong2 v;
             v.x = lds[one_pad(i)];
             v.y = lds[one_pad(i + 1)];
-            v.x = P::finish_fwd(P::WIDE ? guard(v.x, m.K << 1, m.negK << 1) : v.x, m, lazy);
-            v.y = P::finish_fwd(P::WIDE ? guard(v.y, m.K << 1, m.negK << 1) : v.y, m, lazy);
+            v.x = finish_fwd_any<P>(v.x, m, lazy);
+            v.y = finish_fwd_any<P>(v.y, m, lazy);
             *reinterpret_cast<ulonglong2 *>(p + i) = v;
         }
     }
@@ -1358,7 +1381,7 @@ namespace
         {
             // (with the Fast policy the inverse column pass is bound by its instruction stream, 93 % VALU-busy, and wide
             // tiles change nothing; InvWide's 93 instead of 103 instructions per coefficient leave it on its accesses)
-            typedef typename std::conditional<P::WIDE, Fast, P>::type Q;
+            typedef typename std::conditional<P::WIDE != 0, Fast, P>::type Q;
             if constexpr (LOGN1 == 8 && P::INV_WIDE)
             {
                 if (wide_tiles(a))
@@ -1380,7 +1403,7 @@ namespace
             if (n_lp > 0x7fffffffu)
                 return cat::fail(CAT_ERR_LOGIC, "invalid parameters");
             const u32 threads = ctx->n / 2 >= 256 ? 256 : 64;
-            typedef typename std::conditional<P::WIDE, Fast, P>::type Q;
+            typedef typename std::conditional<P::WIDE != 0, Fast, P>::type Q;
             if (forward)
                 hipLaunchKernelGGL((ntt_small<Q, true>), dim3((u32)n_lp), dim3(threads), 0, s, a);
             else
@@ -1399,7 +1422,7 @@ namespace
         {
             if (n_lp > 0x7fffffffu)
                 return cat::fail(CAT_ERR_LOGIC, "invalid parameters");
-            typedef typename std::conditional<P::WIDE, Fast, P>::type QI; // Wide is a forward policy
+            typedef typename std::conditional<P::WIDE != 0, Fast, P>::type QI; // Wide is a forward policy
             const dim3 grid((u32)n_lp);
             if (forward)
                 switch (ctx->log_n)
@@ -1466,7 +1489,7 @@ namespace
                 hipLaunchKernelGGL(ntt_inv_rows8<P::INV_WIDE>, dim3((u32)(groups * chunks)), dim3(256), 0, s, a, chunks);
             }
             else
-                hipLaunchKernelGGL((ntt_inv_rows<typename std::conditional<P::WIDE, Fast, P>::type>),
+                hipLaunchKernelGGL((ntt_inv_rows<typename std::conditional<P::WIDE != 0, Fast, P>::type>),
                                    dim3((u32)row_blocks), dim3(256), 0, s, a);
             cols();
         }
@@ -1477,12 +1500,18 @@ namespace
 
 namespace cat
 {
-    bool ntt_wide(const cat_ctx *ctx, const LimbMap &map, uint32_t n_groups)
+    int ntt_wide(const cat_ctx *ctx, const LimbMap &map, uint32_t n_groups)
     {
+        int level = 2;
         for (uint32_t i = 0; i < n_groups; ++i)
-            if (ctx->hmods[map.id[i]].q >> 60)
-                return false;
-        return true;
+        {
+            const u64 q = ctx->hmods[map.id[i]].q;
+            if (q >> 60)
+                return 0;
+            if ((q >> 57) || !(q >> 35))
+                level = 1;
+        }
+        return level;
     }
 
     // every prime of 36 to 60 bits: the inverse transform's wide ranges (policy InvWide) need 16q <= 2^64 and the
@@ -1581,8 +1610,14 @@ namespace cat
             return launch_policy<Exact>(ctx, forward, a, s, false);
         }
         a.tw = forward ? (const void *)ctx->d_tw3_fwd : (const void *)ctx->d_tw3_inv;
-        if (forward && ctx->log_n >= 12 && ntt_wide(ctx, map, (n_limbs + limb_group - 1) / limb_group))
-            return launch_policy<Wide>(ctx, forward, a, s, fuse && fuse->first_pass_only);
+        if (forward && ctx->log_n >= 12)
+        {
+            const int level = ntt_wide(ctx, map, (n_limbs + limb_group - 1) / limb_group);
+            if (level == 2)
+                return launch_policy<Wider>(ctx, forward, a, s, fuse && fuse->first_pass_only);
+            if (level == 1)
+                return launch_policy<Wide>(ctx, forward, a, s, fuse && fuse->first_pass_only);
+        }
         if (!forward && ctx->log_n >= 12 && ntt_inv_wide(ctx, map, (n_limbs + limb_group - 1) / limb_group))
             return launch_policy<InvWide>(ctx, forward, a, s, false);
         return launch_policy<Fast>(ctx, forward, a, s, fuse && fuse->first_pass_only);

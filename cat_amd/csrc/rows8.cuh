@@ -97,17 +97,19 @@ namespace
     }
 
     // last 8 stages of ND limb-rows held as x[n][a] = row[a * 32 + t]; result x[n][u] = row[8 t + u], values < 4q
-    // WIDE: inputs < 16q, a subtraction of 8q before the even stages only (primes below 2^60)
-    // WIDE with red_r != 0 (NttMod, primes of 36 bits and more): the final reduction from 16q goes by an estimated
+    // WIDE = 1: inputs < 16q, a subtraction of 8q before the even stages only (primes below 2^60)
+    // WIDE = 1 with red_r != 0 (NttMod, primes of 36 bits and more): the final reduction from 16q goes by an estimated
     // quotient and the results are below 2q
-    template <int ND, bool WIDE = false>
+    // WIDE = 2 (primes of 36 to 57 bits, ntt.hip policy Wider): inputs < 36q, no subtraction in any stage (< 68q < 2^64),
+    // the same final reduction
+    template <int ND, int WIDE = 0>
     __device__ __forceinline__ void rm_rows(u64 (&x)[ND][8], const u64 *tw, u64 *xs, u32 t, u64 q, u32 red_r = 0,
                                             u32 red_shift = 0)
     {
         const u64 K = q << 2, negK = 0 - K, nq = 0 - q;
-        rm_stage<ND, 1, WIDE ? 2 : 1>(x, tw, 1, K, negK, nq);
-        rm_stage<ND, 2, WIDE ? 0 : 1>(x, tw, 2, K, negK, nq);
-        rm_stage<ND, 4, WIDE ? 2 : 1>(x, tw, 4, K, negK, nq);
+        rm_stage<ND, 1, (WIDE == 2 ? 0 : WIDE ? 2 : 1)>(x, tw, 1, K, negK, nq);
+        rm_stage<ND, 2, (WIDE ? 0 : 1)>(x, tw, 2, K, negK, nq);
+        rm_stage<ND, 4, (WIDE == 2 ? 0 : WIDE ? 2 : 1)>(x, tw, 4, K, negK, nq);
         const u32 A = t >> 2, c = t & 3;
 #pragma unroll
         for (int n = 0; n < ND; ++n)
@@ -121,9 +123,9 @@ namespace
             for (int b = 0; b < 8; ++b)
                 x[n][b] = xs[(A << 5) | ((b ^ A) << 2) | c]; // element A*32 + 4b + c
         }
-        rm_stage<ND, 1, WIDE ? 0 : 1>(x, tw, 8 + A, K, negK, nq);
-        rm_stage<ND, 2, WIDE ? 2 : 1>(x, tw, 16 + 2 * A, K, negK, nq);
-        rm_stage<ND, 4, WIDE ? 0 : 1>(x, tw, 32 + 4 * A, K, negK, nq);
+        rm_stage<ND, 1, (WIDE ? 0 : 1)>(x, tw, 8 + A, K, negK, nq);
+        rm_stage<ND, 2, (WIDE == 2 ? 0 : WIDE ? 2 : 1)>(x, tw, 16 + 2 * A, K, negK, nq);
+        rm_stage<ND, 4, (WIDE ? 0 : 1)>(x, tw, 32 + 4 * A, K, negK, nq);
         const u32 bh = t & 3; // reader t = A*4 + b_hi holds elements 8t + u
 #pragma unroll
         for (int n = 0; n < ND; ++n)
@@ -137,9 +139,9 @@ namespace
             for (int u = 0; u < 8; ++u)
                 x[n][u] = xs[(u << 5) | (A << 2) | (bh ^ (u & 3))];
         }
-        rm_stage<ND, 2, WIDE ? 2 : 1>(x, tw, 64 + 2 * t, K, negK, nq);
-        rm_stage<ND, 4, WIDE ? 0 : 1>(x, tw, 128 + 2 * t, K, negK, nq, 192 + 2 * t);
-        if (WIDE && red_r != 0)
+        rm_stage<ND, 2, (WIDE == 2 ? 0 : WIDE ? 2 : 1)>(x, tw, 64 + 2 * t, K, negK, nq);
+        rm_stage<ND, 4, (WIDE ? 0 : 1)>(x, tw, 128 + 2 * t, K, negK, nq, 192 + 2 * t);
+        if (WIDE == 2 || (WIDE && red_r != 0))
         {
 #pragma unroll
             for (int n = 0; n < ND; ++n)

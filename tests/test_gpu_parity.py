@@ -403,7 +403,35 @@ def test_switch_key_extreme_operands(cat, oracle, bits, count):
     ctx.close()
 
 
-@pytest.mark.parametrize("bits", [30, 35, 36, 37, 44, 58, 60])
+@pytest.mark.parametrize("polys", [2, 6])
+@pytest.mark.parametrize("log_n", [12, 13, 14, 16])
+def test_guard_free_forward_transform_at_57_bits(cat, oracle, log_n, polys):
+    """Primes of 36 to 57 bits take the forward policy without any guard (csrc/ntt.hip Wider: values grow to 68q < 2^64
+    and one estimated-quotient reduction ends the transform).  The largest such primes, on the single-pass kernels
+    (N = 4096, 8192), the two passes with 64- and 256-row column tiles, the 16-per-thread and the streaming row kernels:
+    all-(q-1), alternating and random inputs, inputs up to 4q - 1, one 36-bit prime beside the 57-bit ones."""
+    n = 1 << log_n
+    primes = oracle.get_primes(2 * n, 57, 3) + oracle.get_primes(2 * n, 36, 1)
+    assert max(primes).bit_length() == 57
+    octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+    ctx = cat.Context(log_n, primes, cat.SCHEME_NONE)
+    qs = np.array(primes, dtype=np.uint64)
+    ids = list(range(len(primes)))
+    rng = np.random.default_rng(5700 + log_n + polys)
+    x = rand_limbs(rng, primes, (polys,), n)
+    x[0] = (qs - 1)[:, None]
+    x[1, :, ::2] = (qs - 1)[:, None]
+    x[1, :, 1::2] = 0
+    exp = octx.ntt_forward(x, ids, lazy=False)
+    assert (host(ctx.ntt_forward(dev(x), lazy=False)) == exp).all()
+    assert (host(ctx.ntt_inverse(dev(exp), lazy=False)) == x).all()
+    x4 = rand_limbs(rng, primes, (polys,), n, mult=4)
+    x4[0] = (4 * qs - 1)[:, None]
+    assert (host(ctx.ntt_forward(dev(x4), lazy=False)) == octx.ntt_forward(x4, ids, lazy=False)).all()
+    ctx.close()
+
+
+@pytest.mark.parametrize("bits", [30, 35, 36, 37, 44, 56, 57, 58, 60])
 def test_wide_row_pass_final_reduction_by_prime_size(cat, oracle, bits):
     """The wide-range row passes end with an estimated-quotient reduction from 16q for primes of 36 bits and more
     (modarith.cuh reduce_below_2q) and with conditional subtractions below that: both sides of the boundary, the

@@ -44,6 +44,31 @@ def test_estimated_quotient_is_exact_or_one_less_from_36_bits():
                 assert 0 <= x - e * q < 2 * q
 
 
+def test_estimated_quotient_holds_for_any_64_bit_operand():
+    """Policy Wider (csrc/ntt.hip: primes of 36 to 57 bits, no guard in any of the 16 stages) ends a forward transform with
+    reduce_below_2q on values up to 68q: the estimate's error does not depend on the size of x, only on b >= 36."""
+    rng = random.Random(57)
+    for bits in range(36, 61):
+        for q in so.get_primes(2 * 4096, bits, 2):
+            top = (1 << 64) - 1
+            xs = [top, top - 1, (top // q) * q, (top // q) * q - 1, 68 * q - 1 if 68 * q <= top else top, 36 * q]
+            xs += [rng.randrange(1 << 64) for _ in range(2000)]
+            for x in xs:
+                x = min(x, top)
+                e = estimate(x, q)
+                assert e < 1 << 32 and x // q - 1 <= e <= x // q, (bits, q, x)
+                assert 0 <= x - e * q < 2 * q
+
+
+def test_guard_free_forward_transform_fits_64_bits_up_to_57_bit_primes():
+    """A forward butterfly adds at most 4q to the larger of its inputs (X' = u + wY < u + 4q, Y' = u + 4q - wY): sixteen
+    stages on inputs below 4q (canonical data, or the key-switch raise's values modulo a prime q_J <= 4q) stay below
+    68q, eight stages (a first-pass-only result) below 36q."""
+    q_max = (1 << 57) - 1
+    assert 4 * q_max + 16 * 4 * q_max < 1 << 64
+    assert not (4 * ((1 << 58) - 1) + 16 * 4 * ((1 << 58) - 1) < 1 << 64)  # 58-bit primes would not fit: the threshold is tight
+
+
 def test_accumulator_bounds():
     a_max, b_max = (1 << 62) - 1, (1 << 60) - 1
     a0, a1, b0, b1 = a_max & 0xffffffff, a_max >> 32, b_max & 0xffffffff, b_max >> 32
