@@ -56,6 +56,7 @@ SIGNATURES = {
     "cat_sub_plain": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "cat_switch_key": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_key_broadcast": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.c_size_t, vp]),
+    "cat_result_gather": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp]),
     "cat_relinearize": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_relinearize_rescale": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "cat_rescale": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]),

@@ -278,6 +278,21 @@ class Context:
                                           key.numel(), root, bucket_words, self._stream()))
         return key
 
+    def result_gather(self, local, comm=None, world=1, out=None):
+        """cat_result_gather: every rank's `local` slice (equal sizes) in rank order -> [world, *local.shape]; comm = an
+        ncclComm_t (integer / c_void_p) of `world` ranks, None = single process."""
+        import torch
+
+        if not local.is_contiguous():
+            raise ValueError("local slice must be contiguous")
+        if out is None:
+            out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        if out.numel() != world * local.numel() or not out.is_contiguous():
+            raise ValueError("destination must hold world x local words")
+        _check(self.lib.cat_result_gather(self.h, C.c_void_p(comm) if isinstance(comm, int) else comm, self._p(local),
+                                          local.numel(), self._p(out), self._stream()))
+        return out
+
     def relinearize(self, ct3, key):
         """ct3: [batch, 3, L, N]; returns a view of the first two polys (updated in place)."""
         b, _, L, _ = ct3.shape

@@ -1,5 +1,5 @@
-// Key replication over RCCL: the only collective of the path, used once per key, outside the steady
-// state.  The reference has no counterpart (single GPU, single process; no nccl/MPI anywhere under native/src).
+// Key replication and result gathering over RCCL: the two collectives of the path, both outside the
+// steady state (keys once at start, results at the end if the caller wants them in one place).  The reference has no counterpart (single GPU, single process; no nccl/MPI anywhere under native/src).
 // librccl is bound at run time (dlopen) so that single-GPU users of libcat_amd.so need no RCCL at all.
 #include "context.hpp"
 
@@ -9,12 +9,14 @@
 namespace
 {
     typedef int (*bcast_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    typedef int (*allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
     typedef const char *(*errstr_fn)(int);
     constexpr int NCCL_UINT64 = 5; // ncclUint64, rccl.h
 
     std::mutex g_mutex;
     bool g_tried = false;
     bcast_fn g_bcast = nullptr;
+    allgather_fn g_allgather = nullptr;
     errstr_fn g_errstr = nullptr;
 
     bool bind_rccl()
@@ -29,6 +31,7 @@ namespace
         g_bcast = (bcast_fn)dlsym(RTLD_DEFAULT, "ncclBroadcast");
         if (g_bcast)
         {
+            g_allgather = (allgather_fn)dlsym(RTLD_DEFAULT, "ncclAllGather");
             g_errstr = (errstr_fn)dlsym(RTLD_DEFAULT, "ncclGetErrorString");
             return true;
         }
@@ -46,6 +49,7 @@ namespace
         if (!h)
             return false;
         g_bcast = (bcast_fn)dlsym(h, "ncclBroadcast");
+        g_allgather = (allgather_fn)dlsym(h, "ncclAllGather");
         g_errstr = (errstr_fn)dlsym(h, "ncclGetErrorString");
         return g_bcast != nullptr;
     }
@@ -78,5 +82,33 @@ extern "C" cat_status cat_key_broadcast(cat_ctx *ctx, void *comm, uint64_t *d_ke
         if (rc != 0)
             return cat::fail(CAT_ERR_HIP, std::string("RCCL error: ") + (g_errstr ? g_errstr(rc) : "ncclBroadcast failed"));
     }
+    return CAT_OK;
+}
+
+extern "C" cat_status cat_result_gather(cat_ctx *ctx, void *comm, const uint64_t *d_local, size_t n_words, uint64_t *d_all,
+                                        cat_stream s)
+{
+    cat::DeviceScope dev;
+    {
+        const cat_status st = dev.enter(ctx);
+        if (st != CAT_OK)
+            return st;
+    }
+    if (n_words == 0)
+        return CAT_OK;
+    if (!d_local || !d_all)
+        return cat::fail(CAT_ERR_INVALID_ARG, "destination is not valid");
+    if (!comm)
+    {
+        // one process: its slice is the whole batch
+        if (d_all != d_local)
+            CAT_HIP(hipMemcpyAsync(d_all, d_local, n_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t)s));
+        return CAT_OK;
+    }
+    if (!bind_rccl() || !g_allgather)
+        return cat::fail(CAT_ERR_LOGIC, "librccl.so is not available");
+    const int rc = g_allgather(d_local, d_all, n_words, NCCL_UINT64, comm, (hipStream_t)s);
+    if (rc != 0)
+        return cat::fail(CAT_ERR_HIP, std::string("RCCL error: ") + (g_errstr ? g_errstr(rc) : "ncclAllGather failed"));
     return CAT_OK;
 }

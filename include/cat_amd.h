@@ -197,6 +197,12 @@ cat_status cat_switch_key(cat_ctx *ctx, uint64_t *d_encrypted, const uint64_t *d
  * when the collective fails.  Asynchronous on stream s like every other call. */
 cat_status cat_key_broadcast(cat_ctx *ctx, void *comm, uint64_t *d_key, size_t n_words, int root, size_t bucket_words,
                              cat_stream s);
+/* No counterpart in the reference either.  The optional second collective: every rank contributes the
+ * n_words words of its result slice at d_local and receives all slices in rank order in d_all (world x n_words words;
+ * ncclAllGather, so equal counts -- a caller with uneven slices pads the short ones).  d_all + rank * n_words may be
+ * d_local (in place).  comm == NULL: a single process, d_all receives a copy of d_local.  Errors as cat_key_broadcast. */
+cat_status cat_result_gather(cat_ctx *ctx, void *comm, const uint64_t *d_local, size_t n_words, uint64_t *d_all,
+                             cat_stream s);
 /* Evaluator::relinearize_internal for size 3 -> 2 (evaluator.cpp:1144-1199): d_ct3 is
  * batch x 3 x L x N; on return the first two polys of each ciphertext hold the result (the caller
  * "resizes" by ignoring the third).  d_key = RelinKeys key of index get_index(2) = 0 (relinkeys.h:58-64). */

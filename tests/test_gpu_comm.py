@@ -69,6 +69,15 @@ def test_bench_communicator_class_on_one_rank():
         ctx.key_broadcast(key, comm.handle, root=0)
         torch.cuda.synchronize()
         assert torch.equal(key, ref)
+        # the second collective: one rank's slice is the whole batch (ncclAllGather on the one-rank communicator, and the
+        # single-process form without one)
+        part = key[:1].contiguous()
+        got = ctx.result_gather(part, comm.handle, world=1)
+        alone = ctx.result_gather(part, None, world=1)
+        torch.cuda.synchronize()
+        assert got.shape == (1,) + tuple(part.shape) and torch.equal(got[0], part) and torch.equal(alone[0], part)
+        with pytest.raises(ValueError, match="world x local"):
+            ctx.result_gather(part, None, world=1, out=torch.empty(3, dtype=torch.int64, device="cuda:0"))
     finally:
         comm.close()
     ctx.close()
