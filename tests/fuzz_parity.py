@@ -48,6 +48,9 @@ def draw_case(rng, max_log_n):
     style = rng.random()
     if style < 0.35:
         bits = [60] * k
+    elif style < 0.60:
+        # every prime of at most 57 bits: the guard-free forward policy (csrc/ntt.hip Wider), with its largest size often
+        bits = [57 if rng.random() < 0.3 else int(rng.integers(max(lo, 36), 58)) for _ in range(k)]
     else:
         bits = [int(rng.integers(lo, 61)) for _ in range(k)]
     t = 0 if scheme == "ckks" else PLAIN_MODULI[int(rng.integers(0, len(PLAIN_MODULI)))]
