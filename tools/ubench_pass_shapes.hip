@@ -155,6 +155,43 @@ __global__ __launch_bounds__(THREADS) void cols_once(const u64 *src, u64 *dst, u
     }
 }
 
+// ---- the 128 x 512 split of N = 65536: a column tile of C columns x ROWS rows with rows RL words long -----------------
+// (ROWS x RL = N; 7 column stages + 9 row stages instead of 8 + 8 would give 512-byte segments to a 512-thread workgroup)
+template <int C, int ROWS, int RL, int THREADS>
+__global__ __launch_bounds__(THREADS) void cols_shape(u64 *buf, u32 polys)
+{
+    const u32 tiles = RL / C;
+    const u32 tile = blockIdx.x % tiles, rest = blockIdx.x / tiles;
+    const u32 poly = rest / LIMBS, limb = rest % LIMBS; // (tile, limb, poly)
+    const size_t off = (size_t)poly * (LIMBS * N) + limb * N + (size_t)tile * C;
+    constexpr int RPT = ROWS * C / THREADS;
+    const u32 c = threadIdx.x % C, tau = threadIdx.x / C;
+    u64 x[RPT];
+#pragma unroll
+    for (int e = 0; e < RPT; ++e)
+        x[e] = ld8<true>(buf + off + (size_t)(e * (THREADS / C) + tau) * RL + c);
+#pragma unroll
+    for (int e = 0; e < RPT; ++e)
+        st8<true>(x[e] + 1, buf + off + (size_t)(e * (THREADS / C) + tau) * RL + c);
+}
+// rows RL words long, R of them per workgroup of 256 threads, 16 B per lane, one trip
+template <int R, int RL>
+__global__ __launch_bounds__(256) void rows_shape(u64 *buf, u32 polys)
+{
+    constexpr int U = R * RL / 2 / 256;
+    u64x2 *p = reinterpret_cast<u64x2 *>(buf + (size_t)blockIdx.x * R * RL) + threadIdx.x;
+    u64x2 x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        x[u] = ld<true>(p + u * 256);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+        x[u].x += 1;
+        st<true>(x[u], p + u * 256);
+    }
+}
+
 struct Row
 {
     double gbps;
@@ -267,6 +304,20 @@ int main(int argc, char **argv)
     COLS_ONCE(128, 1024, false, true)
     COLS_ONCE(8, 256, true, true)
     COLS_ONCE(8, 128, true, true)
+
+#define COLS_SHAPE(C, ROWS, RL, T)                                                                                     \
+    snprintf(name, sizeof name, "cols, one trip: %2d columns (%3d-B segments) x %3d rows of %3d words, %4d threads, nt in place, (tile, limb, poly)", C, C * 8, ROWS, RL, T); \
+    timed(name, [&] { hipLaunchKernelGGL((cols_shape<C, ROWS, RL, T>), dim3(lp * (RL / C)), dim3(T), 0, 0, a, polys); });
+    COLS_SHAPE(32, 256, 256, 512)  // today
+    COLS_SHAPE(64, 256, 256, 1024)
+    COLS_SHAPE(64, 256, 256, 512)  // 32 rows per thread
+    COLS_SHAPE(64, 128, 512, 512)  // the 7 + 9 split
+    COLS_SHAPE(32, 128, 512, 256)
+    COLS_SHAPE(128, 128, 512, 1024)
+    COLS_SHAPE(64, 64, 1024, 256)  // 6 + 10
+    COLS_SHAPE(128, 64, 1024, 512)
+    timed("rows, one trip: 4 rows of 512 words per workgroup of 256 threads (4 x 16 B per lane), nt in place", [&] { hipLaunchKernelGGL((rows_shape<4, 512>), dim3(lp * 32), dim3(256), 0, 0, a, polys); });
+    timed("rows, one trip: 8 rows of 256 words per workgroup of 256 threads (4 x 16 B per lane), nt in place", [&] { hipLaunchKernelGGL((rows_shape<8, 256>), dim3(lp * 32), dim3(256), 0, 0, a, polys); });
 
     // ---- order of the workgroups over the buffer and the stride between objects ------------------------------------
     if (argc <= 2)
