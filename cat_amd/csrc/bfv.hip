@@ -37,8 +37,8 @@ namespace
         u64 copy_stride, copy_obj_stride;
         u32 out_off, mt_limb;
         u64 total; // polys * N
-        // fused tail (template parameter EP of bconv_kernel); constants are per OUTPUT limb
-        const MulOp *ep_c0, *ep_c1;
+        // fused tail (template parameter EP of bconv_kernel)
+        const MulOp *ep_c0, *ep_c1; // EP 3: B mod q_o, -B mod q_o per output limb
         const u64 *ep_in; // EP 2: the Bsk part of the input, [polys][..][N]
         u64 ep_in_stride;
         u64 ep_k0;        // EP 1: -q^-1 mod m_tilde
@@ -50,12 +50,15 @@ namespace
     // over the same coefficients, each needing only values this thread already holds:
     //   0  out = v (and the residue modulo m_tilde when mt_matrix is given: fastbconv_m_tilde, rns.cpp:1092-1131)
     //   1  sm_mrq (rns.cpp:981-1041) on top of fastbconv_m_tilde: r = v_mt * (-q^-1) mod m_tilde, centred;
-    //        out_i = (r * (q mod m_i) + v_i) * m_tilde^-1 mod m_i                  ep_c0 = q mod m_i, ep_c1 = m_tilde^-1 mod m_i
+    //        out_i = (r * (q mod m_i) + v_i) * m_tilde^-1 mod m_i
     //   2  fast_floor tail (rns.cpp:1070-1088): out_i = (in_Bsk_i [* t] + (m_i - v_i)) * q^-1 mod m_i
-    //                                                                              ep_c0 = q^-1 mod m_i, ep_c1 = t mod m_i or null
     //   3  fastbconv_sk tail (rns.cpp:930-977): alpha = (v_sk + (m_sk - in_sk)) * B^-1 mod m_sk, centred;
     //        out_i = v_i + (alpha > m_sk/2 ? (m_sk - alpha) * (B mod q_i) : alpha * (-B mod q_i))      ep_c0 = B, ep_c1 = -B
     // Same values as the separate kernels (cat_sm_mrq keeps the standalone form); one write instead of write + read + write.
+    // Every tail is affine in v, so it costs one more multiply-accumulate before the reduction, not multiplications after
+    // it: EP 1 and 2 come with a matrix of isz + 1 columns that has the tail's factor folded in (build_level) and the
+    // tail's own operand (r, in_Bsk_i) meets the extra column; EP 3 adds alpha x (+-B mod q_i).  Operand bounds of rm_mac:
+    // r and alpha are below a 61-bit prime, in_Bsk_i is a residue below 2^62 (canonical or lazy); at most 31 + 1 terms.
     // W: coefficients per thread (1 or 2).  Two make every global access 16 bytes per lane and every matrix word (a scalar
     // load) serve two dot products; the staged residues then take isz x 4 KB of LDS, so the launcher uses W = 2 up to 16
     // input limbs.
@@ -106,11 +109,62 @@ namespace
         }
         u64 *dst = g.out + obj * g.out_obj_stride + sub * g.out_stride + c;
         // one dot product of the staged residues with a matrix row, both coefficients
-        auto dot = [&](const u64 *row, const DevMod &m, u64 (&v)[W]) {
+        constexpr bool XCOL = EP == 1 || EP == 2; // the matrix carries the tail's column
+        const u32 ms = g.isz + (XCOL ? 1 : 0);    // words per matrix row
+        u64 mt_r[W], alpha[W];
+        bool alpha_neg[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+            mt_r[w] = alpha[w] = 0, alpha_neg[w] = false;
+        // the tail's term of output o: operand ex, multiplier eb
+        auto extra = [&](u32 o, u64 q, const u64 *row, u64 (&ex)[W], u64 (&eb)[W]) {
+            if (EP == 1)
+            {
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    u64 t = mt_r[w];
+                    if (t >= (MT >> 1))
+                        t += q - MT;
+                    ex[w] = t;
+                    eb[w] = row[g.isz];
+                }
+            }
+            if (EP == 2)
+            {
+                ldw<W>(ex, g.ep_in + p * g.ep_in_stride + ((u64)o << g.log_n) + c);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    eb[w] = row[g.isz];
+            }
+            if (EP == 3)
+            {
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    ex[w] = alpha[w];
+                    eb[w] = alpha_neg[w] ? g.ep_c0[o].op : g.ep_c1[o].op;
+                }
+            }
+        };
+        // xo >= 0: with the tail's term of output xo
+        auto dot = [&](const u64 *row, const DevMod &m, u64 (&v)[W], int xo = -1) {
             Acc acc[W];
 #pragma unroll
             for (int w = 0; w < W; ++w)
                 acc[w].lo = acc[w].hi = 0, acc[w].cc = 0;
+            if (EP != 0 && xo >= 0)
+            {
+                u64 ex[W], eb[W];
+                extra((u32)xo, m.q, row, ex, eb);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    u64 mid = 0;
+                    rm_mac(acc[w], mid, ex[w], eb[w]);
+                    rm_fold(acc[w], mid);
+                }
+            }
             u32 j = 0;
             // scaled residues and matrix entries are canonical modulo primes of at most 61 bits: rm_mac's bounds
             for (; j + 2 <= g.isz; j += 2)
@@ -142,11 +196,6 @@ namespace
             for (int w = 0; w < W; ++w)
                 v[w] = barrett128(acc[w].lo, acc[w].hi + acc[w].cc, m.q, m.ratio0, m.ratio1);
         };
-        u64 mt_r[W], alpha[W];
-        bool alpha_neg[W];
-#pragma unroll
-        for (int w = 0; w < W; ++w)
-            mt_r[w] = alpha[w] = 0, alpha_neg[w] = false;
         if (EP == 1)
         {
             u64 acc[W];
@@ -169,7 +218,7 @@ namespace
         {
             const DevMod m = g.mods[g.ep_msk_id];
             u64 conv_sk[W], in_sk[W];
-            dot(g.matrix + (u64)g.osz * g.isz, m, conv_sk);
+            dot(g.matrix + (u64)g.osz * ms, m, conv_sk);
             ldw<W>(in_sk, src + ((u64)g.isz << g.log_n));
 #pragma unroll
             for (int w = 0; w < W; ++w)
@@ -180,55 +229,38 @@ namespace
                     alpha[w] = m.q - alpha[w];
             }
         }
-        // v: canonical residues modulo output prime o (index within the conversion), finished and stored
-        auto finish_store = [&](u32 o, u64 (&v)[W], u64 q) {
-            if (EP == 1)
-            {
-#pragma unroll
-                for (int w = 0; w < W; ++w)
-                {
-                    u64 t = mt_r[w];
-                    if (t >= (MT >> 1))
-                        t += q - MT;
-                    const u64 a = mul_shoup(t, g.ep_c0[o].op, g.ep_c0[o].quo, q);
-                    v[w] = mul_shoup(add_mod(a, v[w], q), g.ep_c1[o].op, g.ep_c1[o].quo, q);
-                }
-            }
-            if (EP == 2)
-            {
-                u64 x[W];
-                ldw<W>(x, g.ep_in + p * g.ep_in_stride + ((u64)o << g.log_n) + c);
-#pragma unroll
-                for (int w = 0; w < W; ++w)
-                {
-                    if (g.ep_c1)
-                        x[w] = mul_shoup(x[w], g.ep_c1[o].op, g.ep_c1[o].quo, q);
-                    v[w] = mul_shoup(x[w] + (q - v[w]), g.ep_c0[o].op, g.ep_c0[o].quo, q);
-                }
-            }
-            if (EP == 3)
-            {
-#pragma unroll
-                for (int w = 0; w < W; ++w)
-                {
-                    const MulOp k = alpha_neg[w] ? g.ep_c0[o] : g.ep_c1[o];
-                    v[w] = add_mod(mul_shoup(alpha[w], k.op, k.quo, q), v[w], q);
-                }
-            }
-            stw<W>(dst + ((u64)(g.out_off + o) << g.log_n), v);
-        };
+        auto finish_store = [&](u32 o, u64 (&v)[W]) { stw<W>(dst + ((u64)(g.out_off + o) << g.log_n), v); };
         u32 o = 0;
         // four output residues at a time: one read of the staged residues serves four dot products, and their folds go
         // through rm_fold4 (3 instructions per accumulator instead of the compiler's 8)
         for (; o + 4 <= g.osz; o += 4)
         {
-            const u64 *row = g.matrix + (u64)o * g.isz;
+            const u64 *row = g.matrix + (u64)o * ms;
             Acc acc[W][4];
 #pragma unroll
             for (int w = 0; w < W; ++w)
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     acc[w][k].lo = acc[w][k].hi = 0, acc[w][k].cc = 0;
+            if (EP != 0)
+            {
+                u64 ex[4][W], eb[4][W];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    extra(o + k, g.mods[g.omap.id[o + k]].q, row + k * ms, ex[k], eb[k]);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    u64 mid[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        mid[k] = 0;
+                        rm_mac(acc[w][k], mid[k], ex[k][w], eb[k][w]);
+                    }
+                    rm_fold4(acc[w][0], acc[w][1], acc[w][2], acc[w][3], mid[0], mid[1], mid[2], mid[3]);
+                }
+            }
             u32 j = 0;
             for (; j + 2 <= g.isz; j += 2)
             {
@@ -238,7 +270,7 @@ namespace
                 u64 m0[4], m1[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    m0[k] = row[k * g.isz + j], m1[k] = row[k * g.isz + j + 1];
+                    m0[k] = row[k * ms + j], m1[k] = row[k * ms + j + 1];
 #pragma unroll
                 for (int w = 0; w < W; ++w)
                 {
@@ -261,7 +293,7 @@ namespace
                     for (int k = 0; k < 4; ++k)
                     {
                         mid[k] = 0;
-                        rm_mac(acc[w][k], mid[k], x0[w], row[k * g.isz + j]);
+                        rm_mac(acc[w][k], mid[k], x0[w], row[k * ms + j]);
                     }
                     rm_fold4(acc[w][0], acc[w][1], acc[w][2], acc[w][3], mid[0], mid[1], mid[2], mid[3]);
                 }
@@ -274,15 +306,15 @@ namespace
 #pragma unroll
                 for (int w = 0; w < W; ++w)
                     v[w] = barrett128(acc[w][k].lo, acc[w][k].hi + acc[w][k].cc, m.q, m.ratio0, m.ratio1);
-                finish_store(o + k, v, m.q);
+                finish_store(o + k, v);
             }
         }
         for (; o < g.osz; ++o)
         {
             const DevMod m = g.mods[g.omap.id[o]];
             u64 v[W];
-            dot(g.matrix + (u64)o * g.isz, m, v);
-            finish_store(o, v, m.q);
+            dot(g.matrix + (u64)o * ms, m, v, (int)o);
+            finish_store(o, v);
         }
         if (EP == 0 && g.mt_matrix)
         {
@@ -524,6 +556,30 @@ namespace cat
         lv.o_inv_mt_Bsk = put_ops(imt);
         lv.o_inv_q_Bsk = put_ops(iq);
         lv.o_t_Bsk = put_ops(tb);
+        // sm_mrq and the fast_floor tail are affine in the converted residue v_o = sum_i s_i (q/q_i) mod m_o:
+        //   ((r (q mod m_o) + v_o) m_tilde^-1,   (x [t] + (m_o - v_o)) q^-1
+        // so each is ONE dot product over L + 1 terms (the tail's own operand r or x against one more column) and one
+        // reduction -- the canonical residue of the same number the reference reaches in three reductions (bconv_kernel)
+        auto mulm = [](u64 a, u64 b, u64 m) { return (u64)((unsigned __int128)a * b % m); };
+        std::vector<u64> m_mrq, m_floor, m_floor_t;
+        for (uint32_t o = 0; o < lv.Bsk; ++o)
+        {
+            const u64 m = hm(lv.map_Bsk.id[o]).q;
+            for (uint32_t i = 0; i < L; ++i)
+            {
+                const u64 e = mp_mod(punc_q[i], m);
+                m_mrq.push_back(mulm(e, imt[o].op, m));
+                const u64 f = mulm(e, iq[o].op, m);
+                m_floor.push_back(f ? m - f : 0);
+                m_floor_t.push_back(f ? m - f : 0);
+            }
+            m_mrq.push_back(mulm(pq[o].op, imt[o].op, m));
+            m_floor.push_back(iq[o].op);
+            m_floor_t.push_back(mulm(tb[o].op, iq[o].op, m));
+        }
+        lv.o_q_to_Bsk_mrq = put_words(m_mrq);
+        lv.o_q_to_Bsk_floor = put_words(m_floor);
+        lv.o_q_to_Bsk_floor_t = put_words(m_floor_t);
         // scalars
         if (!invert_mod(mp_mod(prod_q, MT), MT, inv))
             return fail(CAT_ERR_LOGIC, "invalid rns bases");
@@ -632,7 +688,8 @@ namespace
             g.copy_stride = place->copy_stride;
             g.copy_obj_stride = place->copy_obj_stride;
         }
-        g.matrix = lv.d_blob + lv.o_q_to_Bsk;
+        g.matrix = lv.d_blob + (ep == 1 ? lv.o_q_to_Bsk_mrq : ep == 2 ? (scale == PRE_T ? lv.o_q_to_Bsk_floor_t : lv.o_q_to_Bsk_floor)
+                                                        : lv.o_q_to_Bsk);
         g.mt_matrix = with_mt || ep == 1 ? lv.d_blob + lv.o_q_to_mt : nullptr;
         g.imap = lv.map_q;
         g.omap = lv.map_Bsk;
@@ -645,15 +702,9 @@ namespace
         g.mt_limb = lv.Bsk;
         g.total = polys << ctx->log_n;
         if (ep == 1)
-        {
-            g.ep_c0 = ops_at(lv, lv.o_prod_q_Bsk);
-            g.ep_c1 = ops_at(lv, lv.o_inv_mt_Bsk);
             g.ep_k0 = lv.neg_inv_q_mt;
-        }
         else if (ep == 2)
         {
-            g.ep_c0 = ops_at(lv, lv.o_inv_q_Bsk);
-            g.ep_c1 = scale == PRE_T ? ops_at(lv, lv.o_t_Bsk) : nullptr;
             g.ep_in = in_B;
             g.ep_in_stride = in_B_stride;
         }

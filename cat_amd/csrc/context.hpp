@@ -26,6 +26,10 @@ namespace cat
         size_t o_mtilde_q = 0;     // [L] MulOp: m_tilde * (q/q_i)^-1 mod q_i (the two reference multiplications as one constant)
         size_t o_q_to_Bsk = 0;     // [Bsk][L]: (q/q_i) mod Bsk_o
         size_t o_q_to_mt = 0;      // [L]: (q/q_i) mod m_tilde
+        // the conversion matrix with a tail folded in (bfv.hip bconv_kernel EP 1 / 2): one more column, one reduction per output
+        size_t o_q_to_Bsk_mrq = 0;      // [Bsk][L+1]: (q/q_i) m_tilde^-1 mod Bsk_o | (q mod Bsk_o) m_tilde^-1
+        size_t o_q_to_Bsk_floor = 0;    // [Bsk][L+1]: -(q/q_i) q^-1 mod Bsk_o | q^-1 mod Bsk_o
+        size_t o_q_to_Bsk_floor_t = 0;  // [Bsk][L+1]: the same                | t q^-1 mod Bsk_o
         size_t o_inv_punc_B = 0;   // [B] MulOp: (B/b_i)^-1 mod b_i
         size_t o_B_to_q = 0;       // [L][B]: (B/b_i) mod q_o
         size_t o_B_to_msk = 0;     // [B]: (B/b_i) mod m_sk
