@@ -303,7 +303,8 @@ cat_status cat_fastbconv_m_tilde(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d
 cat_status cat_sm_mrq(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys,
                       cat_stream s); /* rns.cpp:981-1041: Bsk U {m_tilde} -> Bsk */
 cat_status cat_fast_floor(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys,
-                          cat_stream s); /* rns.cpp:1043-1090: q U Bsk -> Bsk */
+                          cat_stream s); /* rns.cpp:1043-1090: q U Bsk -> Bsk; input residues canonical, as the reference
+                                          * requires (values up to 2^62 are accepted: the Bsk part enters a lazy 128-bit sum) */
 cat_status cat_fastbconv_sk(cat_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint32_t L, uint32_t n_polys,
                             cat_stream s); /* rns.cpp:903-979: Bsk -> q */
 
