@@ -194,7 +194,7 @@ namespace
             }
 #pragma unroll
             for (int w = 0; w < W; ++w)
-                v[w] = barrett128(acc[w].lo, acc[w].hi + acc[w].cc, m.q, m.ratio0, m.ratio1);
+                v[w] = reduce128(acc[w].lo, acc[w].hi + acc[w].cc, m.q, m.ratio1, m.r64_quo);
         };
         if (EP == 1)
         {
@@ -305,7 +305,7 @@ namespace
                 u64 v[W];
 #pragma unroll
                 for (int w = 0; w < W; ++w)
-                    v[w] = barrett128(acc[w][k].lo, acc[w][k].hi + acc[w][k].cc, m.q, m.ratio0, m.ratio1);
+                    v[w] = reduce128(acc[w][k].lo, acc[w][k].hi + acc[w][k].cc, m.q, m.ratio1, m.r64_quo);
                 finish_store(o + k, v);
             }
         }

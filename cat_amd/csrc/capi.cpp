@@ -271,11 +271,11 @@ cat_status cat_ctx_create(uint32_t log_n, const uint64_t *primes, uint32_t n_pri
             dm[i].q = hm.q;
             dm[i].ratio0 = hm.ratio0;
             dm[i].ratio1 = hm.ratio1;
+            dm[i].r64_quo = hm.shoup((u64)(0 - hm.ratio1 * hm.q));
             dm[i].inv_n_op = t.inv_n;
             dm[i].inv_n_quo = hm.shoup(t.inv_n);
             dm[i].inv_n_w_op = t.inv_n_w;
             dm[i].inv_n_w_quo = hm.shoup(t.inv_n_w);
-            dm[i].pad = 0;
             std::memcpy(&fwd[i * n], t.fwd.data(), n * sizeof(MulOp));
             std::memcpy(&inv[i * n], t.inv.data(), n * sizeof(MulOp));
             for (size_t j = 0; j < n; ++j)

@@ -69,6 +69,33 @@ def test_guard_free_forward_transform_fits_64_bits_up_to_57_bit_primes():
     assert not (4 * ((1 << 58) - 1) + 16 * 4 * ((1 << 58) - 1) < 1 << 64)  # 58-bit primes would not fit: the threshold is tight
 
 
+def test_reduce128_equals_the_residue_for_any_128_bit_value():
+    """reduce128 (modarith.cuh, the base-conversion kernel's reduction): hi 2^64 + lo mod q as a Shoup product of hi with
+    2^64 mod q plus a Barrett-64 step on lo, two conditional subtractions; restated here word for word in 64-bit
+    arithmetic for primes of 20 to 61 bits (the BEHZ auxiliary primes have 61)."""
+    M = (1 << 64) - 1
+    rng = random.Random(128)
+    for bits in (20, 30, 36, 49, 55, 60, 61):
+        for q in so.get_primes(2 * 4096, bits, 2):
+            ratio1 = (1 << 64) // q                      # high word of floor(2^128 / q)
+            r64 = (0 - ratio1 * q) & M
+            assert r64 == (1 << 64) % q
+            r64_quo = (r64 << 64) // q
+            cases = [(0, 0), (M, M), (M, 0), (0, M), (q - 1, q - 1), (M, q), (1, (1 << 61) - 1)]
+            cases += [(rng.randrange(1 << 64), rng.randrange(1 << 64)) for _ in range(3000)]
+            for lo, hi in cases:
+                t1 = (r64 * hi - ((hi * r64_quo) >> 64) * q) & M
+                t0 = (lo - ((lo * ratio1) >> 64) * q) & M
+                assert t0 < 2 * q and t1 < 2 * q
+                s = t0 + t1
+                assert s < 1 << 64
+                if s >= 2 * q:
+                    s -= 2 * q
+                if s >= q:
+                    s -= q
+                assert s == ((hi << 64) | lo) % q, (bits, q, lo, hi)
+
+
 def test_accumulator_bounds():
     a_max, b_max = (1 << 62) - 1, (1 << 60) - 1
     a0, a1, b0, b1 = a_max & 0xffffffff, a_max >> 32, b_max & 0xffffffff, b_max >> 32
