@@ -14,6 +14,7 @@
 #include "context.hpp"
 
 #include <cstring>
+#include <type_traits>
 
 namespace
 {
@@ -60,8 +61,8 @@ namespace
     // tail's own operand (r, in_Bsk_i) meets the extra column; EP 3 adds alpha x (+-B mod q_i).  Operand bounds of rm_mac:
     // r and alpha are below a 61-bit prime, in_Bsk_i is a residue below 2^62 (canonical or lazy); at most 31 + 1 terms.
     // W: coefficients per thread (1 or 2).  Two make every global access 16 bytes per lane and every matrix word (a scalar
-    // load) serve two dot products; the staged residues then take isz x 4 KB of LDS, so the launcher uses W = 2 up to 16
-    // input limbs.
+    // load) serve two dot products.  This kernel (residues staged in LDS under a run-time index) serves more than 16 input
+    // limbs with W = 1; up to 16 limbs take bconv_reg_kernel below.
     template <int W>
     __device__ __forceinline__ void ldw(u64 (&v)[W], const u64 *p)
     {
@@ -330,6 +331,197 @@ namespace
                 for (int w = 0; w < W; ++w)
                     acc[w] += x[w] * g.mt_matrix[j];
             }
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                acc[w] &= MT - 1;
+            stw<W>(dst + ((u64)g.mt_limb << g.log_n), acc);
+        }
+    }
+
+    // The same conversion for at most IT input limbs (IT = 4, 8, 12, 16), two coefficients per thread, with the scaled residues
+    // in REGISTERS and every loop over the input limbs unrolled: no LDS (the staged residues were private to their thread
+    // anyway, LDS only gave them a run-time index, and 32 KB per workgroup capped the CU at five workgroups), the matrix
+    // words of a block of four outputs are requested together instead of pair by pair behind a wait each.  Limbs beyond
+    // isz contribute a zero residue (their matrix index is clamped, the word read does not matter).
+    template <int EP, int IT>
+    __global__ __launch_bounds__(256) void bconv_reg_kernel(BconvArgs g)
+    {
+        constexpr int W = 2;
+        const u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) * W;
+        if (i >= g.total)
+            return;
+        const u32 c = (u32)(i & ((1u << g.log_n) - 1));
+        const u64 p = i >> g.log_n;
+        const u64 *src = g.in + p * g.in_stride + c;
+        const u64 obj = p / g.grp, sub = p - obj * g.grp;
+        u64 *cpy = g.copy_out ? g.copy_out + obj * g.copy_obj_stride + sub * g.copy_stride + c : nullptr;
+        u64 *dst = g.out + obj * g.out_obj_stride + sub * g.out_stride + c;
+        const u32 last = g.isz - 1;
+        u64 sx[IT][W];
+#pragma unroll
+        for (int j = 0; j < IT; ++j)
+        {
+            sx[j][0] = sx[j][1] = 0;
+            if ((u32)j < g.isz)
+                ldw<W>(sx[j], src + ((u64)j << g.log_n));
+        }
+#pragma unroll
+        for (int j = 0; j < IT; ++j)
+        {
+            if ((u32)j < g.isz)
+            {
+                const u64 q = g.mods[g.imap.id[j]].q;
+                if (cpy)
+                    stw<W>(cpy + ((u64)j << g.log_n), sx[j]);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    sx[j][w] = mul_shoup(sx[j][w], g.inv_punc[j].op, g.inv_punc[j].quo, q);
+            }
+        }
+        constexpr bool XCOL = EP == 1 || EP == 2;
+        const u32 ms = g.isz + (XCOL ? 1 : 0);
+        u64 mt_r[W], alpha[W];
+        bool alpha_neg[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+            mt_r[w] = alpha[w] = 0, alpha_neg[w] = false;
+        auto clamp = [&](int j) { return (u32)j < g.isz ? (u32)j : last; };
+        auto extra = [&](u32 o, u64 q, const u64 *row, u64 (&ex)[W], u64 (&eb)[W]) {
+            if (EP == 1)
+            {
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    u64 t = mt_r[w];
+                    if (t >= (MT >> 1))
+                        t += q - MT;
+                    ex[w] = t;
+                    eb[w] = row[g.isz];
+                }
+            }
+            if (EP == 2)
+            {
+                ldw<W>(ex, g.ep_in + p * g.ep_in_stride + ((u64)o << g.log_n) + c);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    eb[w] = row[g.isz];
+            }
+            if (EP == 3)
+            {
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    ex[w] = alpha[w];
+                    eb[w] = alpha_neg[w] ? g.ep_c0[o].op : g.ep_c1[o].op;
+                }
+            }
+        };
+        // K outputs o .. o + K - 1 (K = 4 or 1); with_tail: the tail's term goes in as well
+        auto block = [&](u32 o, auto kc, bool with_tail, const u64 *row, u64 (&res)[decltype(kc)::value][W]) {
+            constexpr int K = decltype(kc)::value;
+            Acc acc[W][K];
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    acc[w][k].lo = acc[w][k].hi = 0, acc[w][k].cc = 0;
+            if (EP != 0 && with_tail)
+            {
+                u64 ex[K][W], eb[K][W];
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    extra(o + k, g.mods[g.omap.id[o + k]].q, row + k * ms, ex[k], eb[k]);
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                    {
+                        u64 mid = 0;
+                        rm_mac(acc[w][k], mid, ex[k][w], eb[k][w]);
+                        rm_fold(acc[w][k], mid);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < IT; j += 2)
+            {
+                if ((u32)j >= g.isz)
+                    break;
+                u64 m0[K], m1[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    m0[k] = row[k * ms + j], m1[k] = row[k * ms + clamp(j + 1)];
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    u64 mid[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        rm_mac2(acc[w][k], mid[k], sx[j][w], m0[k], sx[j + 1][w], m1[k]);
+                    if constexpr (K == 4)
+                        rm_fold4(acc[w][0], acc[w][1], acc[w][2], acc[w][3], mid[0], mid[1], mid[2], mid[3]);
+                    else
+                        rm_fold(acc[w][0], mid[0]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+            {
+                const DevMod m = with_tail || EP != 3 ? g.mods[g.omap.id[o + k]] : g.mods[g.ep_msk_id];
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    res[k][w] = reduce128(acc[w][k].lo, acc[w][k].hi + acc[w][k].cc, m.q, m.ratio1, m.r64_quo);
+            }
+        };
+        if (EP == 1)
+        {
+            u64 acc[W] = { 0, 0 };
+#pragma unroll
+            for (int j = 0; j < IT; ++j)
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    acc[w] += sx[j][w] * g.mt_matrix[clamp(j)];
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                mt_r[w] = ((acc[w] & (MT - 1)) * g.ep_k0) & (MT - 1);
+        }
+        if (EP == 3)
+        {
+            const DevMod m = g.mods[g.ep_msk_id];
+            u64 conv_sk[1][W], in_sk[W];
+            block(0, std::integral_constant<int, 1>{}, false, g.matrix + (u64)g.osz * ms, conv_sk);
+            ldw<W>(in_sk, src + ((u64)g.isz << g.log_n));
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+            {
+                alpha[w] = mul_shoup(conv_sk[0][w] + (m.q - in_sk[w]), g.ep_k1.op, g.ep_k1.quo, m.q);
+                alpha_neg[w] = alpha[w] > (m.q >> 1);
+                if (alpha_neg[w])
+                    alpha[w] = m.q - alpha[w];
+            }
+        }
+        u32 o = 0;
+        for (; o + 4 <= g.osz; o += 4)
+        {
+            u64 res[4][W];
+            block(o, std::integral_constant<int, 4>{}, true, g.matrix + (u64)o * ms, res);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                stw<W>(dst + ((u64)(g.out_off + o + k) << g.log_n), res[k]);
+        }
+        for (; o < g.osz; ++o)
+        {
+            u64 res[1][W];
+            block(o, std::integral_constant<int, 1>{}, true, g.matrix + (u64)o * ms, res);
+            stw<W>(dst + ((u64)(g.out_off + o) << g.log_n), res[0]);
+        }
+        if (EP == 0 && g.mt_matrix)
+        {
+            u64 acc[W] = { 0, 0 };
+#pragma unroll
+            for (int j = 0; j < IT; ++j)
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    acc[w] += sx[j][w] * g.mt_matrix[clamp(j)];
 #pragma unroll
             for (int w = 0; w < W; ++w)
                 acc[w] &= MT - 1;
@@ -644,20 +836,39 @@ namespace
     {
         if (g.total == 0)
             return CAT_OK;
-        // two coefficients per thread while the staged residues fit 64 KB of LDS (isz <= 16)
-        const bool two = g.isz <= 16 && (g.total & 1) == 0;
-        const dim3 grid(blocks_for(two ? g.total / 2 : g.total)), block(256);
-        const size_t lds = g.isz * 256 * sizeof(u64) * (two ? 2 : 1);
-        switch (ep * 2 + (two ? 1 : 0))
+        // up to 16 input limbs (and an even number of coefficients): residues in registers, two coefficients per thread
+        if (g.isz <= 16 && (g.total & 1) == 0)
+        {
+            const dim3 grid(blocks_for(g.total / 2)), block(256);
+            const int it = (int)((g.isz + 3) / 4);
+#define CAT_BCONV_REG(EP)                                                                                              \
+    switch (it)                                                                                                        \
+    {                                                                                                                  \
+    case 1: hipLaunchKernelGGL((bconv_reg_kernel<EP, 4>), grid, block, 0, s, g); break;                                \
+    case 2: hipLaunchKernelGGL((bconv_reg_kernel<EP, 8>), grid, block, 0, s, g); break;                                \
+    case 3: hipLaunchKernelGGL((bconv_reg_kernel<EP, 12>), grid, block, 0, s, g); break;                               \
+    default: hipLaunchKernelGGL((bconv_reg_kernel<EP, 16>), grid, block, 0, s, g); break;                              \
+    }
+            switch (ep)
+            {
+            case 0: CAT_BCONV_REG(0) break;
+            case 1: CAT_BCONV_REG(1) break;
+            case 2: CAT_BCONV_REG(2) break;
+            default: CAT_BCONV_REG(3) break;
+            }
+#undef CAT_BCONV_REG
+            CAT_HIP(hipGetLastError());
+            return CAT_OK;
+        }
+        // more input limbs: residues staged in LDS under a run-time index, one coefficient per thread
+        const dim3 grid(blocks_for(g.total)), block(256);
+        const size_t lds = g.isz * 256 * sizeof(u64);
+        switch (ep)
         {
         case 0: hipLaunchKernelGGL((bconv_kernel<0, 1>), grid, block, lds, s, g); break;
-        case 1: hipLaunchKernelGGL((bconv_kernel<0, 2>), grid, block, lds, s, g); break;
-        case 2: hipLaunchKernelGGL((bconv_kernel<1, 1>), grid, block, lds, s, g); break;
-        case 3: hipLaunchKernelGGL((bconv_kernel<1, 2>), grid, block, lds, s, g); break;
-        case 4: hipLaunchKernelGGL((bconv_kernel<2, 1>), grid, block, lds, s, g); break;
-        case 5: hipLaunchKernelGGL((bconv_kernel<2, 2>), grid, block, lds, s, g); break;
-        case 6: hipLaunchKernelGGL((bconv_kernel<3, 1>), grid, block, lds, s, g); break;
-        default: hipLaunchKernelGGL((bconv_kernel<3, 2>), grid, block, lds, s, g); break;
+        case 1: hipLaunchKernelGGL((bconv_kernel<1, 1>), grid, block, lds, s, g); break;
+        case 2: hipLaunchKernelGGL((bconv_kernel<2, 1>), grid, block, lds, s, g); break;
+        default: hipLaunchKernelGGL((bconv_kernel<3, 1>), grid, block, lds, s, g); break;
         }
         CAT_HIP(hipGetLastError());
         return CAT_OK;
