@@ -591,14 +591,14 @@ namespace
         const u64 *x = g.x + b * g.in_stride + off, *y = g.y + b * g.in_stride + off;
         const u64 x0 = x[0], x1 = x[poly], y0 = y[0], y1 = y[poly];
         u64 *o = g.out + b * 3 * poly + off;
-        o[0] = mul_mod(x0, y0, m.q, m.ratio0, m.ratio1);
+        o[0] = reduce128(x0 * y0, mulhi64(x0, y0), m.q, m.ratio1, m.r64_quo);
         // the middle term as one 128-bit sum and ONE reduction (operands below 2^63: the sum is below 2^127, and
         // Barrett-128 takes any 128-bit value); the canonical result is that of the reference's two products and add
         u64 lo = 0, hi = 0;
         mac128(lo, hi, x1, y0);
         mac128(lo, hi, x0, y1);
-        o[poly] = barrett128(lo, hi, m.q, m.ratio0, m.ratio1);
-        o[2 * poly] = mul_mod(x1, y1, m.q, m.ratio0, m.ratio1);
+        o[poly] = reduce128(lo, hi, m.q, m.ratio1, m.r64_quo);
+        o[2 * poly] = reduce128(x1 * y1, mulhi64(x1, y1), m.q, m.ratio1, m.r64_quo);
     }
 
     u32 blocks_for(u64 items)
