@@ -127,6 +127,7 @@ namespace
         int use_diag;
         u64 target_stride;
         u32 groups;        // (d+1) * N / 2048
+        u32 nb;            // ks_rows_mac_kernel<.., true>: ciphertexts per workgroup
     };
 
     __device__ __forceinline__ void rm_load8(u64 (&v)[8], const u64 *p)
@@ -142,13 +143,14 @@ namespace
 
     // Every prime of a scheme context is below 2^60 (cat_ctx_create), so the rows run with the wide lazy ranges and
     // their results (< 4q < 2^62) meet rm_mac's operand bound as they are.
-    template <int WIDE>
+    template <int WIDE, bool MULTI>
     __global__ __launch_bounds__(256, 2) void ks_rows_mac_kernel(RowsMacArgs g)
     {
         __shared__ __align__(16) u64 lds[RM_TW_WORDS + RM_X_WORDS];
-        // id -> (group, ciphertext): ids 8 apart share the group (= the key tile) and the XCD
-        const u32 chunk = blockIdx.x / (8 * g.batch), within = blockIdx.x - chunk * 8 * g.batch;
-        const u32 b = within >> 3, grp = chunk * 8 + (within & 7);
+        // id -> (group, ciphertext or run of nb ciphertexts): ids 8 apart share the group (= the key tile) and the XCD
+        const u32 cb = MULTI ? (g.batch + g.nb - 1) / g.nb : g.batch;
+        const u32 chunk = blockIdx.x / (8 * cb), within = blockIdx.x - chunk * 8 * cb;
+        const u32 b0 = (within >> 3) * (MULTI ? g.nb : 1u), grp = chunk * 8 + (within & 7);
         if (grp >= g.groups)
             return;
         const u32 n1 = 1u << (g.log_n - 8), tiles = n1 / RM_ROWS;
@@ -166,114 +168,123 @@ namespace
         const size_t N = (size_t)1 << g.log_n;
         const size_t roff = (size_t)row * 256;
 
-        Acc acc[2][8];
+        // MULTI: the workgroup keeps its staged twiddles for g.nb ciphertexts in a row (launches with many more workgroups
+        // than the card holds and few digits: the 48 KB of twiddles are a quarter of such a workgroup's traffic)
+        for (u32 bb = 0; bb < (MULTI ? g.nb : 1u); ++bb)
+        {
+            const u32 b = b0 + bb;
+            if (MULTI && b >= g.batch)
+                break;
+            Acc acc[2][8];
 #pragma unroll
-        for (int cidx = 0; cidx < 2; ++cidx)
+            for (int cidx = 0; cidx < 2; ++cidx)
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                acc[cidx][u].lo = acc[cidx][u].hi = 0, acc[cidx][u].cc = 0;
-        const u64 *kbase = g.key + (size_t)ki * N + roff + 8 * t;
-        const u64 *ebase = g.ext + ((size_t)b * (g.d + 1) + I) * g.d * N + roff + t;
-        // one or two digits: their middle sums share one 64-bit word per accumulator and are folded once
-        auto mac = [&](const u64 (&x0)[8], u32 J0, const u64 (&x1)[8], u32 J1, bool two) {
+                for (int u = 0; u < 8; ++u)
+                    acc[cidx][u].lo = acc[cidx][u].hi = 0, acc[cidx][u].cc = 0;
+            const u64 *kbase = g.key + (size_t)ki * N + roff + 8 * t;
+            const u64 *ebase = g.ext + ((size_t)b * (g.d + 1) + I) * g.d * N + roff + t;
+            // one or two digits: their middle sums share one 64-bit word per accumulator and are folded once
+            auto mac = [&](const u64 (&x0)[8], u32 J0, const u64 (&x1)[8], u32 J1, bool two) {
+#pragma unroll
+                for (int cidx = 0; cidx < 2; ++cidx)
+                {
+                    u64 kv[8], mid[8];
+                    rm_load8(kv, kbase + (size_t)(J0 * 2 + cidx) * g.k * N);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                    {
+                        mid[u] = 0;
+                        rm_mac(acc[cidx][u], mid[u], x0[u], kv[u]);
+                    }
+                    if (two)
+                    {
+                        rm_load8(kv, kbase + (size_t)(J1 * 2 + cidx) * g.k * N);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            rm_mac(acc[cidx][u], mid[u], x1[u], kv[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        rm_fold(acc[cidx][u], mid[u]);
+                }
+            };
+            const bool diag = g.use_diag && I < g.d;
+            if (diag)
+            {
+                u64 xv[8];
+                rm_load8(xv, g.target + (size_t)b * g.target_stride + (size_t)I * N + roff + 8 * t);
+                mac(xv, I, xv, I, false);
+            }
+            const u32 cnt = diag ? g.d - 1 : g.d;
+            u32 jj = 0;
+            for (; jj + 2 <= cnt; jj += 2)
+            {
+                const u32 J0 = (diag && jj >= I) ? jj + 1 : jj, J1 = (diag && jj + 1 >= I) ? jj + 2 : jj + 1;
+                u64 x[2][8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+                {
+                    x[0][a] = ebase[(size_t)J0 * N + a * 32];
+                    x[1][a] = ebase[(size_t)J1 * N + a * 32];
+                }
+                // key words of component 0 are requested before the transform (behind the digit data in the memory
+                // queue), those of component 1 while component 0 is being accumulated
+                const u64 *kp0 = kbase + (size_t)(J0 * 2) * g.k * N, *kp1 = kbase + (size_t)(J1 * 2) * g.k * N;
+                u64 ka[8], kb[8];
+                rm_load8(ka, kp0);
+                rm_load8(kb, kp1);
+                rm_rows<2, WIDE>(x, tw, xs, t, q, red_r, red_shift);
+#pragma unroll
+                for (int cidx = 0; cidx < 2; ++cidx)
+                {
+                    u64 kc[8], kd[8], mid[8];
+                    if (cidx == 0)
+                    {
+                        rm_load8(kc, kp0 + (size_t)g.k * N);
+                        rm_load8(kd, kp1 + (size_t)g.k * N);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        rm_mac2(acc[cidx][u], mid[u], x[0][u], ka[u], x[1][u], kb[u]);
+#pragma unroll
+                    for (int u = 0; u < 8; u += 4)
+                        rm_fold4(acc[cidx][u], acc[cidx][u + 1], acc[cidx][u + 2], acc[cidx][u + 3], mid[u], mid[u + 1],
+                                 mid[u + 2], mid[u + 3]);
+                    if (cidx == 0)
+                    {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            ka[u] = kc[u], kb[u] = kd[u];
+                    }
+                }
+            }
+            if (jj < cnt)
+            {
+                const u32 J0 = (diag && jj >= I) ? jj + 1 : jj;
+                u64 x[1][8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+                    x[0][a] = ebase[(size_t)J0 * N + a * 32];
+                rm_rows<1, WIDE>(x, tw, xs, t, q, red_r, red_shift);
+                mac(x[0], J0, x[0], J0, false);
+            }
+            // d < 256: the reference's lazy counter never triggers an intermediate reduction (:2619-2707)
+            const DevMod m = g.mods[ki];
 #pragma unroll
             for (int cidx = 0; cidx < 2; ++cidx)
             {
-                u64 kv[8], mid[8];
-                rm_load8(kv, kbase + (size_t)(J0 * 2 + cidx) * g.k * N);
+                u64 *o = g.prod + (((size_t)b * 2 + cidx) * (g.d + 1) + I) * N + roff + 8 * t;
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int i = 0; i < 4; ++i)
                 {
-                    mid[u] = 0;
-                    rm_mac(acc[cidx][u], mid[u], x0[u], kv[u]);
-                }
-                if (two)
-                {
-                    rm_load8(kv, kbase + (size_t)(J1 * 2 + cidx) * g.k * N);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        rm_mac(acc[cidx][u], mid[u], x1[u], kv[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    rm_fold(acc[cidx][u], mid[u]);
-            }
-        };
-        const bool diag = g.use_diag && I < g.d;
-        if (diag)
-        {
-            u64 xv[8];
-            rm_load8(xv, g.target + (size_t)b * g.target_stride + (size_t)I * N + roff + 8 * t);
-            mac(xv, I, xv, I, false);
-        }
-        const u32 cnt = diag ? g.d - 1 : g.d;
-        u32 jj = 0;
-        for (; jj + 2 <= cnt; jj += 2)
-        {
-            const u32 J0 = (diag && jj >= I) ? jj + 1 : jj, J1 = (diag && jj + 1 >= I) ? jj + 2 : jj + 1;
-            u64 x[2][8];
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-            {
-                x[0][a] = ebase[(size_t)J0 * N + a * 32];
-                x[1][a] = ebase[(size_t)J1 * N + a * 32];
-            }
-            // key words of component 0 are requested before the transform (behind the digit data in the memory
-            // queue), those of component 1 while component 0 is being accumulated
-            const u64 *kp0 = kbase + (size_t)(J0 * 2) * g.k * N, *kp1 = kbase + (size_t)(J1 * 2) * g.k * N;
-            u64 ka[8], kb[8];
-            rm_load8(ka, kp0);
-            rm_load8(kb, kp1);
-            rm_rows<2, WIDE>(x, tw, xs, t, q, red_r, red_shift);
-#pragma unroll
-            for (int cidx = 0; cidx < 2; ++cidx)
-            {
-                u64 kc[8], kd[8], mid[8];
-                if (cidx == 0)
-                {
-                    rm_load8(kc, kp0 + (size_t)g.k * N);
-                    rm_load8(kd, kp1 + (size_t)g.k * N);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    rm_mac2(acc[cidx][u], mid[u], x[0][u], ka[u], x[1][u], kb[u]);
-#pragma unroll
-                for (int u = 0; u < 8; u += 4)
-                    rm_fold4(acc[cidx][u], acc[cidx][u + 1], acc[cidx][u + 2], acc[cidx][u + 3], mid[u], mid[u + 1],
-                             mid[u + 2], mid[u + 3]);
-                if (cidx == 0)
-                {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        ka[u] = kc[u], kb[u] = kd[u];
+                    ulonglong2 r;
+                    const Acc &e0 = acc[cidx][2 * i], &e1 = acc[cidx][2 * i + 1];
+                    r.x = barrett128(e0.lo, e0.hi + e0.cc, m.q, m.ratio0, m.ratio1);
+                    r.y = barrett128(e1.lo, e1.hi + e1.cc, m.q, m.ratio0, m.ratio1);
+                    reinterpret_cast<ulonglong2 *>(o)[i] = r;
                 }
             }
-        }
-        if (jj < cnt)
-        {
-            const u32 J0 = (diag && jj >= I) ? jj + 1 : jj;
-            u64 x[1][8];
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-                x[0][a] = ebase[(size_t)J0 * N + a * 32];
-            rm_rows<1, WIDE>(x, tw, xs, t, q, red_r, red_shift);
-            mac(x[0], J0, x[0], J0, false);
-        }
-        // d < 256: the reference's lazy counter never triggers an intermediate reduction (:2619-2707)
-        const DevMod m = g.mods[ki];
-#pragma unroll
-        for (int cidx = 0; cidx < 2; ++cidx)
-        {
-            u64 *o = g.prod + (((size_t)b * 2 + cidx) * (g.d + 1) + I) * N + roff + 8 * t;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-            {
-                ulonglong2 r;
-                const Acc &e0 = acc[cidx][2 * i], &e1 = acc[cidx][2 * i + 1];
-                r.x = barrett128(e0.lo, e0.hi + e0.cc, m.q, m.ratio0, m.ratio1);
-                r.y = barrett128(e1.lo, e1.hi + e1.cc, m.q, m.ratio0, m.ratio1);
-                reinterpret_cast<ulonglong2 *>(o)[i] = r;
-            }
+        
         }
     }
 
@@ -951,15 +962,26 @@ namespace cat
             g.use_diag = ckks ? 1 : 0;
             g.target_stride = target_stride;
             g.groups = (u32)((u64)rns * (N / (RM_ROWS * 256)));
-            const u64 blocks = (u64)((g.groups + 7) / 8) * 8 * batch;
+            // few digits (the 48 KB of staged twiddles weigh as much as a workgroup's own data: d = 3, N = 8192, batch 256
+            // gains 2.8 %, d = 8 0.5 %, d >= 15 nothing or less) and far more workgroups than the card holds (512): two or
+            // four ciphertexts per workgroup share its staged twiddles, as long as about four rounds of workgroups remain
+            u32 nb = 1;
+            while (d <= 8 && nb < 4 && (u64)g.groups * batch / (2 * nb) >= 2048 && 2 * nb <= batch)
+                nb *= 2;
+            g.nb = nb;
+            const u64 blocks = (u64)((g.groups + 7) / 8) * 8 * ((batch + nb - 1) / nb);
             if (blocks > 0x7fffffffu)
                 return fail(CAT_ERR_LOGIC, "invalid parameters");
             if (!wide)
                 return fail(CAT_ERR_LOGIC, "invalid parameters"); // unreachable: scheme contexts hold primes < 2^60
-            if (wide == 2)
-                hipLaunchKernelGGL(ks_rows_mac_kernel<2>, dim3((u32)blocks), dim3(256), 0, s, g);
+            if (nb > 1 && wide == 2)
+                hipLaunchKernelGGL((ks_rows_mac_kernel<2, true>), dim3((u32)blocks), dim3(256), 0, s, g);
+            else if (nb > 1)
+                hipLaunchKernelGGL((ks_rows_mac_kernel<1, true>), dim3((u32)blocks), dim3(256), 0, s, g);
+            else if (wide == 2)
+                hipLaunchKernelGGL((ks_rows_mac_kernel<2, false>), dim3((u32)blocks), dim3(256), 0, s, g);
             else
-                hipLaunchKernelGGL(ks_rows_mac_kernel<1>, dim3((u32)blocks), dim3(256), 0, s, g);
+                hipLaunchKernelGGL((ks_rows_mac_kernel<1, false>), dim3((u32)blocks), dim3(256), 0, s, g);
             CAT_HIP(hipGetLastError());
         }
         else

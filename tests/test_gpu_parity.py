@@ -374,6 +374,25 @@ def test_switch_key_fused_kernel_prime_sizes(cat, oracle, log_n, bits, count, ba
     ctx.close()
 
 
+def test_switch_key_several_ciphertexts_per_workgroup(cat, oracle):
+    """With few digits and thousands of workgroups the fused key-switch kernel keeps its staged twiddles for two or four
+    ciphertexts in a row (keyswitch.hip, ks_rows_mac_kernel<.., true>): 1030 ciphertexts at N = 4096, L = 3 take four per
+    workgroup with a ragged last run, one 60-bit chain (policy Wide) and one 50-bit chain (Wider)."""
+    log_n, n, batch = 12, 4096, 1030
+    for bits in (60, 50):
+        primes = list(reversed(oracle.get_primes(2 * n, bits, 4)))
+        octx = oracle.Context(log_n, primes, oracle.SCHEME_CKKS)
+        ctx = cat.Context(log_n, primes, cat.SCHEME_CKKS)
+        key = octx.relin_key(octx.secret_key(11), 12)
+        L = 3
+        enc = np.stack([octx.uniform(L, 2, 7000 + b) for b in range(batch)])
+        tgt = np.stack([octx.uniform(L, 1, 9000 + b)[0] for b in range(batch)])
+        got = host(ctx.switch_key(dev(enc), dev(tgt), dev(key)))
+        for b in list(range(0, batch, 37)) + [batch - 3, batch - 2, batch - 1]:
+            assert (got[b] == octx.switch_key_inplace(enc[b], tgt[b], key)).all(), (bits, b)
+        ctx.close()
+
+
 @pytest.mark.parametrize("bits,count", [(60, 8), (60, 25), (59, 25), (60, 64), (55, 64)])
 def test_switch_key_extreme_operands(cat, oracle, bits, count):
     """Largest operands the lazy accumulators of the fused key-switch kernel can meet: every key word and every
