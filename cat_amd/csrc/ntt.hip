@@ -1206,7 +1206,11 @@ namespace
         }
     }
 
-    template <class P, int LOGN>
+    // FUSED: with the sources and epilogues of NttFuse (the "round" source of mod-down and rescale, the dual source and
+    // the one- and two-term finish of relinearize + rescale; not the key-switch raise, whose row pass is the fused
+    // key-switch kernel): at N = 4096 and 8192 these steps, too, cross HBM once.  A separate instantiation so that the
+    // plain transform keeps its registers.
+    template <class P, int LOGN, bool FUSED = false>
     __global__ __launch_bounds__(OneCfg<LOGN>::THREADS, OneCfg<LOGN>::WAVES) void ntt_fwd_one(NttArgs a)
     {
         typedef OneCfg<LOGN> C;
@@ -1222,9 +1226,23 @@ namespace
             u64 x[C::SETS][16];
 #pragma unroll
             for (int set = 0; set < C::SETS; ++set)
+            {
+                if constexpr (FUSED)
+                {
+                    const Source in = source(a, w, 0, P::WIDE != 0);
+                    auto idx = [&](int e) { return e * Q + set * T + threadIdx.x; };
+                    if (a.src2)
+                        load16_dual(x[set], in, source2(a, w, 0), a.inv_mod[a.src_qidx * a.kdim + w.mod], idx);
+                    else
+                        in.load16(x[set], idx);
+                }
+                else
+                {
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    x[set][e] = p[e * Q + set * T + threadIdx.x];
+                    for (int e = 0; e < 16; ++e)
+                        x[set][e] = p[e * Q + set * T + threadIdx.x];
+                }
+            }
 #pragma unroll
             for (int set = 0; set < C::SETS; ++set)
             {
@@ -1251,6 +1269,41 @@ namespace
         fwd_one_round<P, LOGN, K + 8, 1>(lds, tw, m);
         __syncthreads();
         const bool lazy = a.lazy != 0;
+        if (FUSED && a.ep_dest)
+        {
+            // the finish steps of fwd_rows_tile on the transformed limb t (< 4q), which is not stored
+            const u32 b = w.poly / a.ep_S, si = w.poly - b * a.ep_S;
+            const u64 in_limb = (u64)w.limb << LOGN;
+            const u64 *other = a.ep_other + b * a.ep_other_b + si * a.ep_other_s + in_limb;
+            const u64 *other2 = a.ep_other2 ? a.ep_other2 + b * a.ep_other2_b + si * a.ep_other2_s + in_limb : nullptr;
+            u64 *dest = a.ep_dest + b * a.ep_dest_b + si * a.ep_dest_s + in_limb;
+            const MulOp inv = a.inv_mod[a.ep_qidx * a.kdim + w.mod];
+            const MulOp inv2 = a.ep_other2 ? a.inv_mod[a.ep_qidx2 * a.kdim + w.mod] : inv;
+            const u64 q4 = m.q << 2;
+#pragma unroll
+            for (int j = 0; j < N / (2 * T); ++j)
+            {
+                const u32 i = 2 * (j * T + threadIdx.x);
+                const u64 t0 = finish_fwd_any<P>(lds[one_pad(i)], m, true), t1 = finish_fwd_any<P>(lds[one_pad(i + 1)], m, true);
+                ulonglong2 o = *reinterpret_cast<const ulonglong2 *>(other + i), v;
+                if (other2)
+                {
+                    const ulonglong2 o2 = *reinterpret_cast<const ulonglong2 *>(other2 + i);
+                    o.x += mul_shoup(o2.x, inv2.op, inv2.quo, m.q);
+                    o.y += mul_shoup(o2.y, inv2.op, inv2.quo, m.q);
+                }
+                v.x = mul_shoup(o.x + q4 - t0, inv.op, inv.quo, m.q);
+                v.y = mul_shoup(o.y + q4 - t1, inv.op, inv.quo, m.q);
+                if (a.ep_acc && !other2)
+                {
+                    const ulonglong2 d = *reinterpret_cast<const ulonglong2 *>(dest + i);
+                    v.x = add_mod(v.x, d.x, m.q);
+                    v.y = add_mod(v.y, d.y, m.q);
+                }
+                *reinterpret_cast<ulonglong2 *>(dest + i) = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < N / (2 * T); ++j)
         {
@@ -1416,6 +1469,20 @@ namespace
         // N = 8192, inverse 0.835 -> 0.818 and 0.898 -> 0.892 ms.  N = 16384 (128 KB of LDS, one workgroup per CU: its load,
         // compute and store phases do not overlap with anything) measured 0.980 / 1.147 ms against 0.848 / 0.882 ms for
         // the two passes and stays on them.
+        // Forward transforms with a fused "round" / dual source or a fused finish (mod-down, rescale, relinearize + rescale)
+        // take the FUSED instantiation; the key-switch raise (first pass only) stays on the column kernel.
+        if constexpr (std::is_base_of<Fast, P>::value)
+        if (ctx->log_n <= 13 && forward && !first_only && (a.ep_dest || a.src) && (!a.src || a.src_kind == 1) && !a.skip_diag)
+        {
+            if (n_lp > 0x7fffffffu)
+                return cat::fail(CAT_ERR_LOGIC, "invalid parameters");
+            if (ctx->log_n == 12)
+                hipLaunchKernelGGL((ntt_fwd_one<P, 12, true>), dim3((u32)n_lp), dim3(OneCfg<12>::THREADS), 0, s, a);
+            else
+                hipLaunchKernelGGL((ntt_fwd_one<P, 13, true>), dim3((u32)n_lp), dim3(OneCfg<13>::THREADS), 0, s, a);
+            CAT_HIP(hipGetLastError());
+            return CAT_OK;
+        }
         if constexpr (std::is_base_of<Fast, P>::value)
         if (ctx->log_n <= 13 && !first_only && !a.ep_dest && !a.src2 &&
             (forward ? !a.src : (!a.src || (a.src_kind == 0 && a.limb_group == 1))))
